@@ -1,0 +1,134 @@
+"""ctypes binding of ``lib/libaau.so`` (C ABI declared in ``include/aau.h``).
+
+This is the only place the host side touches native code.  There is NO fallback:
+if the library is missing or a call fails, an exception is raised (``AauError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB_PATH = os.path.join(PKG, "lib", "libaau.so")
+HEADER = os.path.join(ROOT, "include", "aau.h")
+
+STAT_REPLICAS = 32
+PROF_FAMILIES = 4
+PROF_NAMES = ("igemm", "wgrad", "elementwise", "loss_optim")
+
+
+class AauError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """``aau_conv_desc`` (include/aau.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "Cin", "src_pitch", "Ho", "Wo", "Cout", "dst_pitch", "KH", "KW",
+        "stride", "pad", "dil", "Cpad", "shuffle2x2", "accumulate", "relu")]
+
+
+class PackEntry(C.Structure):
+    """``aau_pack_entry`` (include/aau.h)."""
+    _fields_ = [("src_off", C.c_int64), ("dst_off", C.c_int64), ("R", C.c_int32), ("T", C.c_int32),
+                ("C", C.c_int32), ("Cpad", C.c_int32), ("s_r", C.c_int32), ("s_t", C.c_int32),
+                ("s_c", C.c_int32), ("t_flip", C.c_int32), ("R2", C.c_int32), ("s_r2", C.c_int32),
+                ("blk_begin", C.c_int64)]
+
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_int64
+F = C.c_float
+U64 = C.c_uint64
+
+# name -> argtypes (all return int unless noted)
+_SIGS = {
+    "aau_prof_enable": [I],
+    "aau_prof_collect": [P, P, P],
+    "aau_conv_igemm": [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P],
+    "aau_conv_wgrad": [C.POINTER(ConvDesc), P, P, P, P],
+    "aau_conv1_fwd": [P, P, P, P, I, I, I, I, P],
+    "aau_conv1_wgrad": [P, P, P, I, I, I, I, P],
+    "aau_pack_weights": [P, P, P, I, L, P],
+    "aau_bn_finalize": [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
+    "aau_bn_fold_eval": [P, P, P, P, P, P, I, F, P],
+    "aau_bn_act": [P, I, P, I, P, P, L, I, I, L, F, U64, P],
+    "aau_maxpool2": [P, I, P, I, I, I, I, I, P],
+    "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, U64, P],
+    "aau_bn_bwd_apply": [P, I, P, I, P, P, P, P, P, P, L, I, P],
+    "aau_gap_fwd": [P, I, P, P, I, I, I, P],
+    "aau_gap_bwd": [P, P, I, I, I, I, P],
+    "aau_spatial_sum": [P, I, P, P, I, I, I, P],
+    "aau_gate_psi": [P, P, P, P, P, P, P, P, P, L, I, P],
+    "aau_gate_apply": [P, I, P, P, P, P, P, I, L, I, P],
+    "aau_gate_bwd1": [P, I, P, I, P, P, P, P, P, I, P, P, L, I, P],
+    "aau_gate_bwd2": [P] * 23 + [L, I, P],
+    "aau_gate_bwd3": [P] * 17 + [L, I, P],
+    "aau_outconv_fwd": [P, I, P, P, P, L, I, P],
+    "aau_outconv_bwd": [P, I, P, P, P, I, P, P, L, I, P],
+    "aau_colsum": [P, I, P, L, I, P],
+    "aau_criterion": [P, P, P, P, P, I, I, I, I, F, F, F, P],
+    "aau_seg_metrics": [P, P, P, P, I, I, I, F, P],
+    "aau_grad_sqnorm": [P, L, F, P, P],
+    "aau_adamw_step": [P, P, P, P, L, P, P, F, F, F, F, F, F, F, P],
+    "aau_f32_to_bf16": [P, P, L, P],
+    "aau_bf16_to_f32": [P, P, L, P],
+    "aau_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
+    "aau_nhwc_to_nchw": [P, I, P, I, I, I, I, P],
+    "aau_hflip_f32": [P, P, I, I, I, P],
+    "aau_tta_merge": [P, P, P, I, I, I, P],
+}
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/aau.h."""
+    with open(HEADER) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(aau_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> C.CDLL:
+    """Load the library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AauError(f"{LIB_PATH} not found: run `python __graft_entry__.py` / build() first "
+                           "(there is no non-HIP fallback)")
+        l = C.CDLL(LIB_PATH)
+        l.aau_last_error.restype = C.c_char_p
+        l.aau_last_error.argtypes = []
+        l.aau_version.restype = C.c_int
+        l.aau_version.argtypes = []
+        for name, sig in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = sig
+            fn.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().aau_last_error().decode(errors="replace")
+        raise AauError(f"{what or 'aau call'} failed (rc={rc}): {msg}")
+
+
+def fn(name: str):
+    return getattr(lib(), name)
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().aau_prof_enable(1 if on else 0), "aau_prof_enable")
+
+
+def prof_collect() -> dict:
+    ms = (C.c_double * PROF_FAMILIES)()
+    n = (C.c_int64 * PROF_FAMILIES)()
+    fl = (C.c_double * PROF_FAMILIES)()
+    check(lib().aau_prof_collect(ms, n, fl), "aau_prof_collect")
+    return {PROF_NAMES[i]: {"ms": ms[i], "launches": n[i], "flops": fl[i]} for i in range(PROF_FAMILIES)}

@@ -1,0 +1,63 @@
+"""Builds the gfx950 shared library ``lib/libaau.so`` (C ABI: include/aau.h) in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so
+travels to the GPU box with the snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libaau.so")
+SOURCES = ["runtime.hip", "igemm.hip", "wgrad.hip", "bn.hip", "pointwise.hip", "gate.hip", "loss.hip", "optim.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+         "-Wno-unused-result"]
+
+
+def _newer(src: str, dst: str) -> bool:
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    deps = [os.path.join(ROOT, "include", "aau.h"), os.path.join(CSRC, "common.h")]
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for src, rc, out in ex.map(compile_one, jobs):
+                if verbose and out.strip():
+                    print(out, file=sys.stderr)
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

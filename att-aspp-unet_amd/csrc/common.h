@@ -1,0 +1,74 @@
+// Shared device/host helpers for the gfx950 kernels (internal; the ABI is include/aau.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "aau.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+namespace aau {
+
+// 16-B loads of out-of-image taps / rows past the tensor are redirected to this page
+static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+// ---- bf16 <-> f32 (round to nearest even; plain casts keep NaN a NaN, see guide) ----
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const u32x4& v, float f[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float f[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// counter-based uniform in [0,1) for dropout: keyed by (seed, element index)
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// ---- host side: errors + launch profiling ----
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+struct ProfScope {  // brackets one launch with events when profiling is on
+    ProfScope(int family, double flops, hipStream_t s);
+    ~ProfScope();
+    int idx;
+    hipStream_t stream;
+};
+
+}  // namespace aau
+
+#define AAU_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            aau::set_error(__VA_ARGS__);            \
+            return AAU_E_INVALID;                   \
+        }                                           \
+    } while (0)

@@ -1,0 +1,348 @@
+// Attention gate (pipeline:85-92): x * sigmoid(BN1(psi(relu(BN(Wg g) + BN(Wx x))))).
+// The two 1x1 convolutions run on the MFMA kernel; everything between them is one
+// HBM pass per BatchNorm barrier (training-mode statistics force the cuts):
+//   gate_psi   : s = relu(bn(zg)+bn(zx)); psi_pre = <wpsi, s>; sum / sumsq of psi_pre
+//   gate_apply : alpha = sigmoid(bn1(psi_pre)); out = x * alpha (written into the concat slot)
+// and the mirrored three backward passes.
+#include "common.h"
+
+namespace aau {
+
+struct CGMap3 {
+    int CG, PL, T;
+    __device__ __host__ explicit CGMap3(int C) {
+        CG = C >> 3;
+        PL = 256 / CG;
+        if (PL < 1) PL = 1;
+        T = CG * PL;
+    }
+};
+__device__ __forceinline__ void block_sum8c(float acc[8], float* red, const CGMap3& mp, int tid) {
+    __syncthreads();
+    if (tid < mp.T) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < mp.CG) {
+        for (int pl = 1; pl < mp.PL; ++pl) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += red[(pl * mp.CG + tid) * 8 + j];
+        }
+    }
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block-wide sum of one float per thread, result on thread 0
+__device__ __forceinline__ float block_sum1(float v, float* s4) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+__device__ __forceinline__ void ldf8g(const float* p, float f[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+}
+
+// one thread per pixel
+__global__ __launch_bounds__(256) void gate_psi_kernel(const unsigned short* zg, const unsigned short* zx,
+                                                       const float* sg, const float* hg, const float* sx,
+                                                       const float* hx, const float* wpsi, float* psi_pre,
+                                                       float* stats, int64_t M, int F) {
+    extern __shared__ float sm[];  // [5][F]
+    float* p_sg = sm; float* p_hg = sm + F; float* p_sx = sm + 2 * F; float* p_hx = sm + 3 * F; float* p_w = sm + 4 * F;
+    __shared__ float s4[4];
+    for (int i = threadIdx.x; i < F; i += 256) {
+        p_sg[i] = sg[i]; p_hg[i] = hg[i]; p_sx[i] = sx[i]; p_hx[i] = hx[i]; p_w[i] = wpsi[i];
+    }
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int f = 0; f < F; f += 8) {
+            float a[8], b[8];
+            unpack8(*(const u32x4*)(zg + m * F + f), a);
+            unpack8(*(const u32x4*)(zx + m * F + f), b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float s = fmaxf(a[j] * p_sg[f + j] + p_hg[f + j] + b[j] * p_sx[f + j] + p_hx[f + j], 0.f);
+                acc += s * p_w[f + j];
+            }
+        }
+        psi_pre[m] = acc;
+        t1 += acc;
+        t2 += acc * acc;
+    }
+    if (stats) {
+        const float a = block_sum1(t1, s4);
+        const float b = block_sum1(t2, s4);
+        if (threadIdx.x == 0) {
+            float* r = stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2;
+            atomicAdd(r, a);
+            atomicAdd(r + 1, b);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gate_apply_kernel(const unsigned short* x, int xp, const float* psi_pre,
+                                                         const float* scale1, const float* shift1, float* alpha,
+                                                         unsigned short* out, int op, int64_t M, int C) {
+    const int CG = C >> 3;
+    const int64_t total = M * CG;
+    const float sc = scale1[0], sh = shift1[0];
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+        const int64_t m = v / CG;
+        const int cgi = (int)(v - m * CG);
+        const float a = 1.f / (1.f + expf(-(psi_pre[m] * sc + sh)));
+        if (cgi == 0 && alpha) alpha[m] = a;
+        float f[8];
+        unpack8(*(const u32x4*)(x + m * xp + cgi * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= a;
+        *(u32x4*)(out + m * op + cgi * 8) = pack8(f);
+    }
+}
+
+// one thread per pixel: dx = dout*alpha ; dq = <dout, x> * alpha(1-alpha) ; red1 += (dq, dq*psihat)
+__global__ __launch_bounds__(256) void gate_bwd1_kernel(const unsigned short* dout, int dop, const unsigned short* x,
+                                                        int xp, const float* alpha, const float* psi_pre,
+                                                        const float* mean1, const float* invstd1,
+                                                        unsigned short* dx, int dxp, float* dq, float* red1,
+                                                        int64_t M, int C) {
+    __shared__ float s4[4];
+    const float mu = mean1[0], is = invstd1[0];
+    float t1 = 0.f, t2 = 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+        const float a = alpha[m];
+        float dot = 0.f;
+        for (int c = 0; c < C; c += 8) {
+            float g[8], xv[8];
+            unpack8(*(const u32x4*)(dout + m * dop + c), g);
+            unpack8(*(const u32x4*)(x + m * xp + c), xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dot += g[j] * xv[j]; g[j] *= a; }
+            *(u32x4*)(dx + m * dxp + c) = pack8(g);
+        }
+        const float q = dot * a * (1.f - a);
+        dq[m] = q;
+        t1 += q;
+        t2 += q * (psi_pre[m] - mu) * is;
+    }
+    const float a = block_sum1(t1, s4);
+    const float b = block_sum1(t2, s4);
+    if (threadIdx.x == 0) {
+        float* r = red1 + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2;
+        atomicAdd(r, a);
+        atomicAdd(r + 1, b);
+    }
+}
+
+// channel-group threads: ds, dwpsi, per-channel sums for the two branch BNs
+__global__ __launch_bounds__(256) void gate_bwd2_kernel(
+    const float* dq, const float* psi_pre, const float* red1, const float* gamma1, const float* mean1,
+    const float* invstd1, const unsigned short* zg, const unsigned short* zx, const float* sg, const float* hg,
+    const float* sx, const float* hx, const float* mean_g, const float* invstd_g, const float* mean_x,
+    const float* invstd_x, const float* wpsi, unsigned short* ds, float* dwpsi, float* redg, float* redx,
+    float* dgamma1, float* dbeta1, int64_t M, int F, int64_t ppb) {
+    __shared__ float sred[256 * 8];
+    const CGMap3 mp(F);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float r1 = 0.f, r2 = 0.f;
+    for (int r = 0; r < AAU_STAT_REPLICAS; ++r) { r1 += red1[2 * r]; r2 += red1[2 * r + 1]; }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (dbeta1) dbeta1[0] += r1;
+        if (dgamma1) dgamma1[0] += r2;
+    }
+    const float k0 = gamma1[0] * invstd1[0], k1 = r1 / (float)M, k2 = r2 / (float)M;
+    const float mu1 = mean1[0], is1 = invstd1[0];
+    float a_w[8], a_s[8], a_g[8], a_x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_w[j] = a_s[j] = a_g[j] = a_x[j] = 0.f;
+    if (tid < mp.T) {
+        float v_sg[8], v_hg[8], v_sx[8], v_hx[8], v_w[8], v_mg[8], v_ig[8], v_mx[8], v_ix[8];
+        ldf8g(sg + c, v_sg); ldf8g(hg + c, v_hg); ldf8g(sx + c, v_sx); ldf8g(hx + c, v_hx); ldf8g(wpsi + c, v_w);
+        ldf8g(mean_g + c, v_mg); ldf8g(invstd_g + c, v_ig); ldf8g(mean_x + c, v_mx); ldf8g(invstd_x + c, v_ix);
+        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+            const float ph = (psi_pre[m] - mu1) * is1;
+            const float dp = k0 * (dq[m] - k1 - ph * k2);
+            float a[8], b[8], o[8];
+            unpack8(*(const u32x4*)(zg + m * F + c), a);
+            unpack8(*(const u32x4*)(zx + m * F + c), b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float s = a[j] * v_sg[j] + v_hg[j] + b[j] * v_sx[j] + v_hx[j];
+                const float sr = fmaxf(s, 0.f);
+                const float d = s > 0.f ? dp * v_w[j] : 0.f;
+                a_w[j] += dp * sr;
+                a_s[j] += d;
+                a_g[j] += d * (a[j] - v_mg[j]) * v_ig[j];
+                a_x[j] += d * (b[j] - v_mx[j]) * v_ix[j];
+                o[j] = d;
+            }
+            *(u32x4*)(ds + m * F + c) = pack8(o);
+        }
+    }
+    const int rep = blockIdx.x % AAU_STAT_REPLICAS;
+    block_sum8c(a_w, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(dwpsi + c + j, a_w[j]);
+    }
+    block_sum8c(a_s, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(redg + (size_t)rep * 2 * F + c + j, a_s[j]);
+            atomicAdd(redx + (size_t)rep * 2 * F + c + j, a_s[j]);
+        }
+    }
+    block_sum8c(a_g, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(redg + (size_t)rep * 2 * F + F + c + j, a_g[j]);
+    }
+    block_sum8c(a_x, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(redx + (size_t)rep * 2 * F + F + c + j, a_x[j]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gate_bwd3_kernel(
+    const unsigned short* ds, const unsigned short* zg, const unsigned short* zx, const float* gamma_g,
+    const float* mean_g, const float* invstd_g, const float* redg, const float* gamma_x, const float* mean_x,
+    const float* invstd_x, const float* redx, unsigned short* dzg, unsigned short* dzx, float* dgamma_g,
+    float* dbeta_g, float* dgamma_x, float* dbeta_x, int64_t M, int F) {
+    extern __shared__ float sm[];  // [6][F]
+    float* g0 = sm; float* g1 = sm + F; float* g2 = sm + 2 * F;
+    float* x0 = sm + 3 * F; float* x1 = sm + 4 * F; float* x2 = sm + 5 * F;
+    for (int c = threadIdx.x; c < F; c += 256) {
+        float a = 0.f, b = 0.f, a2 = 0.f, b2 = 0.f;
+        for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
+            a += redg[(size_t)r * 2 * F + c]; b += redg[(size_t)r * 2 * F + F + c];
+            a2 += redx[(size_t)r * 2 * F + c]; b2 += redx[(size_t)r * 2 * F + F + c];
+        }
+        g0[c] = gamma_g[c] * invstd_g[c]; g1[c] = a / (float)M; g2[c] = b / (float)M;
+        x0[c] = gamma_x[c] * invstd_x[c]; x1[c] = a2 / (float)M; x2[c] = b2 / (float)M;
+        if (blockIdx.x == 0) {
+            if (dbeta_g) dbeta_g[c] += a;
+            if (dgamma_g) dgamma_g[c] += b;
+            if (dbeta_x) dbeta_x[c] += a2;
+            if (dgamma_x) dgamma_x[c] += b2;
+        }
+    }
+    __syncthreads();
+    const int CG = F >> 3;
+    const int64_t total = M * CG;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+        const int64_t m = v / CG;
+        const int c = (int)(v - m * CG) * 8;
+        float d[8], a[8], b[8], og[8], ox[8];
+        unpack8(*(const u32x4*)(ds + m * F + c), d);
+        unpack8(*(const u32x4*)(zg + m * F + c), a);
+        unpack8(*(const u32x4*)(zx + m * F + c), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float zhg = (a[j] - mean_g[c + j]) * invstd_g[c + j];
+            const float zhx = (b[j] - mean_x[c + j]) * invstd_x[c + j];
+            og[j] = g0[c + j] * (d[j] - g1[c + j] - zhg * g2[c + j]);
+            ox[j] = x0[c + j] * (d[j] - x1[c + j] - zhx * x2[c + j]);
+        }
+        *(u32x4*)(dzg + m * F + c) = pack8(og);
+        *(u32x4*)(dzx + m * F + c) = pack8(ox);
+    }
+}
+
+static inline int grid1(int64_t n, int cap = 2048) {
+    int64_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace aau
+
+using namespace aau;
+#define CHK_F(fn, C) AAU_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) <= 2048, fn ": channels=%d must be a multiple of 8 in [8, 2048]", (int)(C))
+
+extern "C" int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float* sg, const float* hg,
+                            const float* sx, const float* hx, const float* wpsi, float* psi_pre, float* stats,
+                            int64_t M, int F, void* stream) {
+    AAU_REQUIRE(zg && zx && sg && hg && sx && hx && wpsi && psi_pre && M > 0, "aau_gate_psi: bad args");
+    CHK_F("aau_gate_psi", F);
+    ProfScope prof(2, 2.0 * M * F, (hipStream_t)stream);
+    hipLaunchKernelGGL(gate_psi_kernel, dim3(grid1(M)), dim3(256), 5 * F * sizeof(float), (hipStream_t)stream, zg, zx,
+                       sg, hg, sx, hx, wpsi, psi_pre, stats, M, F);
+    return check_launch("aau_gate_psi");
+}
+
+extern "C" int aau_gate_apply(const aau_bf16* x, int x_pitch, const float* psi_pre, const float* scale1,
+                              const float* shift1, float* alpha, aau_bf16* out, int out_pitch, int64_t M, int C,
+                              void* stream) {
+    AAU_REQUIRE(x && psi_pre && scale1 && shift1 && out && M > 0, "aau_gate_apply: bad args");
+    CHK_F("aau_gate_apply", C);
+    AAU_REQUIRE(x_pitch % 8 == 0 && out_pitch % 8 == 0, "aau_gate_apply: pitch");
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(gate_apply_kernel, dim3(grid1(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, x_pitch,
+                       psi_pre, scale1, shift1, alpha, out, out_pitch, M, C);
+    return check_launch("aau_gate_apply");
+}
+
+extern "C" int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x_pitch,
+                             const float* alpha, const float* psi_pre, const float* mean1, const float* invstd1,
+                             aau_bf16* dx, int dx_pitch, float* dq, float* red1, int64_t M, int C, void* stream) {
+    AAU_REQUIRE(dout && x && alpha && psi_pre && mean1 && invstd1 && dx && dq && red1 && M > 0,
+                "aau_gate_bwd1: bad args");
+    CHK_F("aau_gate_bwd1", C);
+    AAU_REQUIRE(dout_pitch % 8 == 0 && x_pitch % 8 == 0 && dx_pitch % 8 == 0, "aau_gate_bwd1: pitch");
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(gate_bwd1_kernel, dim3(grid1(M)), dim3(256), 0, (hipStream_t)stream, dout, dout_pitch, x,
+                       x_pitch, alpha, psi_pre, mean1, invstd1, dx, dx_pitch, dq, red1, M, C);
+    return check_launch("aau_gate_bwd1");
+}
+
+extern "C" int aau_gate_bwd2(const float* dq, const float* psi_pre, const float* red1, const float* gamma1,
+                             const float* mean1, const float* invstd1, const aau_bf16* zg, const aau_bf16* zx,
+                             const float* sg, const float* hg, const float* sx, const float* hx,
+                             const float* mean_g, const float* invstd_g, const float* mean_x,
+                             const float* invstd_x, const float* wpsi, aau_bf16* ds, float* dwpsi, float* redg,
+                             float* redx, float* dgamma1, float* dbeta1, int64_t M, int F, void* stream) {
+    AAU_REQUIRE(dq && psi_pre && red1 && gamma1 && mean1 && invstd1 && zg && zx && sg && hg && sx && hx && mean_g &&
+                    invstd_g && mean_x && invstd_x && wpsi && ds && dwpsi && redg && redx && M > 0,
+                "aau_gate_bwd2: bad args");
+    CHK_F("aau_gate_bwd2", F);
+    const CGMap3 mp(F);
+    int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    const int64_t ppb = (M + b - 1) / b;
+    b = (M + ppb - 1) / ppb;
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(gate_bwd2_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dq, psi_pre, red1,
+                       gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x, invstd_x, wpsi, ds,
+                       dwpsi, redg, redx, dgamma1, dbeta1, M, F, ppb);
+    return check_launch("aau_gate_bwd2");
+}
+
+extern "C" int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_bf16* zx, const float* gamma_g,
+                             const float* mean_g, const float* invstd_g, const float* redg, const float* gamma_x,
+                             const float* mean_x, const float* invstd_x, const float* redx, aau_bf16* dzg,
+                             aau_bf16* dzx, float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x,
+                             int64_t M, int F, void* stream) {
+    AAU_REQUIRE(ds && zg && zx && gamma_g && mean_g && invstd_g && redg && gamma_x && mean_x && invstd_x && redx &&
+                    dzg && dzx && M > 0, "aau_gate_bwd3: bad args");
+    CHK_F("aau_gate_bwd3", F);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(gate_bwd3_kernel, dim3(grid1(M * (F / 8))), dim3(256), 6 * F * sizeof(float),
+                       (hipStream_t)stream, ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x,
+                       redx, dzg, dzx, dgamma_g, dbeta_g, dgamma_x, dbeta_x, M, F);
+    return check_launch("aau_gate_bwd3");
+}

@@ -1,0 +1,378 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (forward and data-gradient).
+//
+//   dst[m][q] = epi( sum_{tap,c} src[gather(m,tap)][c] * wpk[q][tap][c] )
+//
+// GEMM view: M = N*Ho*Wo output pixels, N = Cout, K = taps x Cin.  The MFMA A operand is
+// the WEIGHT tile (rows = output channels) and the B operand the gathered ACTIVATION
+// tile (columns = pixels), so v_mfma_f32_16x16x32_bf16 leaves each lane with 4
+// consecutive output channels of one pixel: the NHWC store is an 8-byte packed write
+// and the per-channel BatchNorm statistics reduce over the 16 lanes of a DPP row.
+//
+// Staging: both tiles go global -> LDS with global_load_lds_dwordx4 (16 B per lane, no
+// VGPR round trip).  The LDS image is lane-linear, so the bank-conflict swizzle is
+// applied to the per-lane SOURCE address and undone on the ds_read_b128 side (same
+// XOR).  Out-of-image taps, rows past M and channels past Cin read a zero page.
+// Two LDS buffers: the loads of K-step t+1 are in flight during the MFMAs of step t.
+//
+// Replaces: Conv2d inside ConvBNReLU (pipeline:63), the ASPP 1x1 / dilated 3x3 / pool /
+// projection convs (:71-78), the gate 1x1 convs (:88-89), ConvTranspose2d(2,2) (:101,
+// as a GEMM with N = 4*Co and a pixel-shuffle store) and their input gradients.
+#include "common.h"
+
+namespace aau {
+
+
+// physical 16-B slot of logical chunk `lc` in LDS row `row` (an involution)
+template <int BK>
+__device__ __forceinline__ int swz(int row, int lc) {
+    if constexpr (BK == 64) {
+        return lc ^ ((row >> 1) & 7);
+    } else {
+        return lc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+    }
+}
+
+struct IgemmArgs {
+    aau_conv_desc d;
+    const unsigned short* src;
+    const unsigned short* wpk;
+    unsigned short* dst;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    float* stats;
+    int M;
+    int nchunk;  // Cpad / BK
+};
+
+template <int BK, int BQ>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+    constexpr int BP = (BQ == 96) ? 128 : 256;
+    constexpr int SLOTS = BK / 8;            // 16-B slots per LDS row
+    constexpr int RPI = 64 / SLOTS;          // rows covered by one wave-wide glds
+    constexpr int NA = BP / (4 * RPI);       // activation loads per thread per K-step
+    constexpr int NW = (BQ + 4 * RPI - 1) / (4 * RPI);  // weight loads per thread (last may be partial)
+    constexpr int MI = 4, NI = 3;            // wave tile: 64 pixels x 48 channels
+    constexpr int KSUB = BK / 32;
+
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BQ + BP) * BK];
+    auto sW = [&](int buf) -> unsigned short* { return smem + buf * ((BQ + BP) * BK); };
+    auto sA = [&](int buf) -> unsigned short* { return smem + buf * ((BQ + BP) * BK) + BQ * BK; };
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wp = (BQ == 96) ? (wave >> 1) : wave;
+    const int wq = (BQ == 96) ? (wave & 1) : 0;
+
+    // XCD-aware tile order: consecutive tile ids (same pixel tile, different channel
+    // tiles / neighbouring pixel tiles) share an XCD's L2.  Bijective remap.
+    const int ntq = (d.Cout + BQ - 1) / BQ;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tq = bid % ntq;
+    const int tp = bid / ntq;
+    const int q0 = tq * BQ;
+    const int m0 = tp * BP;
+
+    const unsigned short* zero = (const unsigned short*)g_zero_page;
+    const int HoWo = d.Ho * d.Wo;
+
+    // ---- per-thread row bookkeeping for the activation gather ----
+    int pix0[NA];   // n*H*W
+    int yx0[NA];    // (y0 << 16) | (x0 & 0xffff), y0/x0 = out*stride - pad; y0 = -32768 marks "row past M"
+    const int slot = lane % SLOTS;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (i * 4 + wave) * RPI + lane / SLOTS;
+        const int m = m0 + row;
+        if (m < a.M) {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int yo = rem / d.Wo;
+            const int xo = rem - yo * d.Wo;
+            pix0[i] = n * d.H * d.W;
+            yx0[i] = ((yo * d.stride - d.pad) << 16) | ((xo * d.stride - d.pad) & 0xffff);
+        } else {
+            pix0[i] = 0;
+            yx0[i] = (int)0x80000000;
+        }
+    }
+    // logical chunk this lane fetches for each of its rows (swizzle on the source side)
+    int lcA[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) lcA[i] = swz<BK>((i * 4 + wave) * RPI + lane / SLOTS, slot);
+    int lcW[NW];
+    int qrow[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int row = (j * 4 + wave) * RPI + lane / SLOTS;
+        lcW[j] = swz<BK>(row, slot);
+        qrow[j] = (row < BQ && q0 + row < d.Cout) ? (q0 + row) : -1;
+    }
+
+    const int T = d.KH * d.KW;
+
+    // ---- active taps: a tap whose every row of this tile is out of the image is skipped ----
+    unsigned tapmask = (T >= 32) ? 0xffffffffu : ((1u << T) - 1u);
+    if (d.dil > 1) {
+        unsigned mine = 0;
+        for (int t = 0; t < T; ++t) {
+            const int dy = (t / d.KW) * d.dil, dx = (t % d.KW) * d.dil;
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int y = (yx0[i] >> 16) + dy, x = (short)(yx0[i] & 0xffff) + dx;
+                any |= (yx0[i] != (int)0x80000000) && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+            }
+            if (any) mine |= 1u << t;
+        }
+        __shared__ unsigned s_mask;
+        if (tid == 0) s_mask = 0;
+        __syncthreads();
+        if (mine) atomicOr(&s_mask, mine);
+        __syncthreads();
+        tapmask = __builtin_amdgcn_readfirstlane(s_mask);
+        __syncthreads();
+        if (tapmask == 0) tapmask = 1;  // still run one (all-zero) step so the epilogue sees zeros
+    }
+
+    const unsigned short* rowptr[NA];
+    auto set_tap = [&](int tap) {
+        const int dy = (tap / d.KW) * d.dil, dx = (tap % d.KW) * d.dil;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int y = (yx0[i] >> 16) + dy, x = (short)(yx0[i] & 0xffff) + dx;
+            const bool ok = (yx0[i] != (int)0x80000000) && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+            rowptr[i] = ok ? a.src + (int64_t)(pix0[i] + y * d.W + x) * d.src_pitch : nullptr;
+        }
+    };
+
+    auto stage = [&](int buf, int tap, int chunk) {
+        const int c0 = chunk * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int ch = c0 + lcA[i] * 8;
+            const unsigned short* g = (rowptr[i] != nullptr && ch < d.Cin) ? rowptr[i] + ch : zero;
+            unsigned short* l = sA(buf) + (i * 4 + wave) * RPI * BK;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if ((j * 4 + wave) * RPI < BQ) {  // wave-uniform
+                const int ch = c0 + lcW[j] * 8;
+                const unsigned short* g = (qrow[j] >= 0)
+                    ? a.wpk + ((int64_t)qrow[j] * T + tap) * d.Cpad + ch : zero;
+                unsigned short* l = sW(buf) + (j * 4 + wave) * RPI * BK;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15;   // fragment row (pixel for B operand, channel for A operand)
+    const int fk = lane >> 4;   // k-group
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk) {
+            bf16x8 wf[NI], af[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = wq * 48 + ni * 16 + fr;
+                wf[ni] = *(const bf16x8*)(sW(buf) + row * BK + swz<BK>(row, kk * 4 + fk) * 8);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wp * 64 + mi * 16 + fr;
+                af[mi] = *(const bf16x8*)(sA(buf) + row * BK + swz<BK>(row, kk * 4 + fk) * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop over (active tap, channel chunk) ----
+    unsigned mask = tapmask;
+    int tap = __builtin_ctz(mask);
+    mask &= mask - 1;
+    int chunk = 0;
+    set_tap(tap);
+    stage(0, tap, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        int ntap = tap, nchk = chunk + 1;
+        bool more = true;
+        if (nchk == a.nchunk) {
+            nchk = 0;
+            if (mask) {
+                ntap = __builtin_ctz(mask);
+                mask &= mask - 1;
+                set_tap(ntap);
+            } else {
+                more = false;
+            }
+        }
+        if (more) stage(buf ^ 1, ntap, nchk);
+        compute(buf);
+        if (!more) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+        tap = ntap;
+        chunk = nchk;
+    }
+
+    // ---- epilogue ----
+    // lane holds acc[ni][mi][r] = D[channel q0 + wq*48 + ni*16 + 4*fk + r][pixel m0 + wp*64 + mi*16 + fr]
+    const bool want_stats = a.stats != nullptr;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wp * 64 + mi * 16 + fr;
+        const bool mok = m < a.M;
+        int64_t pixel = m;
+        int n = 0, yo = 0, xo = 0;
+        if (d.shuffle2x2 && mok) {
+            n = m / HoWo;
+            const int rem = m - n * HoWo;
+            yo = rem / d.Wo;
+            xo = rem - yo * d.Wo;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int q = q0 + wq * 48 + ni * 16 + 4 * fk;
+            if (!mok || q >= d.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+            if (want_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[ni][r] += v[r]; s2[ni][r] += v[r] * v[r]; }
+            }
+            if (a.bias) {
+                const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (a.scale) {
+                const f32x4 sc = *(const f32x4*)(a.scale + q);
+                const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+            }
+            unsigned short* out;
+            if (d.shuffle2x2) {
+                const int Co = d.Cout >> 2;
+                const int pos = q / Co, co = q - pos * Co;
+                const int64_t op = ((int64_t)n * (2 * d.Ho) + (2 * yo + (pos >> 1))) * (2 * d.Wo) + (2 * xo + (pos & 1));
+                out = a.dst + op * d.dst_pitch + co;
+            } else {
+                out = a.dst + pixel * d.dst_pitch + q;
+            }
+            if (d.accumulate) {
+                const u32x2 old = *(const u32x2*)out;
+                v[0] += __uint_as_float(old[0] << 16);
+                v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                v[2] += __uint_as_float(old[1] << 16);
+                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+            }
+            if (d.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            u32x2 pk;
+            pk[0] = pack2(v[0], v[1]);
+            pk[1] = pack2(v[2], v[3]);
+            *(u32x2*)out = pk;
+        }
+    }
+
+    if (want_stats) {
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x1 = s1[ni][r], x2 = s2[ni][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    x1 += __shfl_xor(x1, o, 64);
+                    x2 += __shfl_xor(x2, o, 64);
+                }
+                const int q = q0 + wq * 48 + ni * 16 + 4 * fk + r;
+                if (fr == 0 && q < d.Cout) {
+                    atomicAdd(st + q, x1);
+                    atomicAdd(st + d.Cout + q, x2);
+                }
+            }
+        }
+    }
+}
+
+template <int BK, int BQ>
+static int launch(const IgemmArgs& a, hipStream_t s) {
+    constexpr int BP = (BQ == 96) ? 128 : 256;
+    const int ntq = (a.d.Cout + BQ - 1) / BQ;
+    const int ntp = (a.M + BP - 1) / BP;
+    const int64_t grid = (int64_t)ntq * ntp;
+    if (grid <= 0 || grid > 0x7fffffff) {
+        set_error("aau_conv_igemm: grid %lld out of range", (long long)grid);
+        return AAU_E_INVALID;
+    }
+    hipLaunchKernelGGL((igemm_kernel<BK, BQ>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    return check_launch("aau_conv_igemm");
+}
+
+}  // namespace aau
+
+extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
+                              aau_bf16* dst, const float* bias, const float* scale, const float* shift,
+                              float* stats, void* stream) {
+    using namespace aau;
+    AAU_REQUIRE(d && src && wpk && dst, "aau_conv_igemm: null pointer");
+    AAU_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0, "aau_conv_igemm: Cin=%d must be a positive multiple of 8", d->Cin);
+    AAU_REQUIRE(d->Cout > 0 && d->Cout % 8 == 0, "aau_conv_igemm: Cout=%d must be a positive multiple of 8", d->Cout);
+    AAU_REQUIRE(d->Cpad >= d->Cin && d->Cpad % 32 == 0, "aau_conv_igemm: Cpad=%d must be a multiple of 32 >= Cin", d->Cpad);
+    AAU_REQUIRE(d->src_pitch >= d->Cin && d->src_pitch % 8 == 0, "aau_conv_igemm: src_pitch=%d", d->src_pitch);
+    AAU_REQUIRE(d->dst_pitch % 4 == 0, "aau_conv_igemm: dst_pitch=%d must be a multiple of 4", d->dst_pitch);
+    AAU_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH * d->KW <= 16, "aau_conv_igemm: taps %dx%d", d->KH, d->KW);
+    AAU_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "aau_conv_igemm: empty shape");
+    AAU_REQUIRE(d->H < 32768 && d->W < 32768, "aau_conv_igemm: spatial dims must be < 32768");
+    AAU_REQUIRE((int64_t)d->N * d->H * d->W < 0x7fffffff && (int64_t)d->N * d->Ho * d->Wo < 0x7fffffff,
+                "aau_conv_igemm: pixel count overflows int32");
+    AAU_REQUIRE((scale == nullptr) == (shift == nullptr), "aau_conv_igemm: scale and shift come together");
+    AAU_REQUIRE(!d->shuffle2x2 || (d->Cout % 32 == 0), "aau_conv_igemm: shuffle2x2 needs Cout %% 32 == 0");
+    AAU_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)wpk & 15) == 0 && ((uintptr_t)dst & 7) == 0,
+                "aau_conv_igemm: pointers must be 16-byte (src, wpk) / 8-byte (dst) aligned");
+    IgemmArgs a;
+    a.d = *d;
+    a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
+    a.M = d->N * d->Ho * d->Wo;
+    const bool bk64 = (d->Cpad % 64 == 0);
+    a.nchunk = d->Cpad / (bk64 ? 64 : 32);
+    const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
+    ProfScope prof(0, flops, (hipStream_t)stream);
+    const bool narrow = d->Cout <= 48;
+    if (bk64) return narrow ? launch<64, 48>(a, (hipStream_t)stream) : launch<64, 96>(a, (hipStream_t)stream);
+    return narrow ? launch<32, 48>(a, (hipStream_t)stream) : launch<32, 96>(a, (hipStream_t)stream);
+}

@@ -1,0 +1,124 @@
+// Optimiser step and weight packing over FLAT fp32 buffers (all 103 parameter tensors
+// live back to back in one allocation, so clip_grad_norm_ + AdamW are three launches):
+//   pipeline:323  torch.nn.utils.clip_grad_norm_(params, 1.0)   -> aau_grad_sqnorm + coefficient
+//   pipeline:302  torch.optim.AdamW(lr, betas (.9,.999), eps 1e-8, weight_decay 5e-4)
+//   pipeline:322/324 GradScaler.unscale_ / skipped step on inf -> inv_scale + finite check
+// and the per-step fp32 -> bf16 repack of the convolution weights into the GEMM operand
+// layouts of igemm.hip (forward: rows = Cout; data-gradient: rows = Cin, taps flipped).
+#include "common.h"
+
+namespace aau {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, int64_t n, float inv_scale, float* out) {
+    __shared__ float s4[4];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)g)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float t = v[k] * inv_scale; acc += t * t; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n4 * 4; i < n; ++i) { const float t = g[i] * inv_scale; acc += t * t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, s4[0] + s4[1] + s4[2] + s4[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, float* m, float* v, const float* g, int64_t n,
+                                                    const float* norm_ws, const int64_t* step_dev, float lr,
+                                                    float b1, float b2, float eps, float wd, float max_norm,
+                                                    float inv_scale) {
+    const float sq = norm_ws[0];
+    if (!(sq < INFINITY)) return;  // inf / nan gradients: skip the step (GradScaler semantics)
+    const float total = sqrtf(sq);
+    float coef = max_norm > 0.f ? max_norm / (total + 1e-6f) : 1.f;
+    coef = fminf(coef, 1.f) * inv_scale;
+    const double t = (double)(step_dev[0] + 1);  // bias corrections in double, as the Python-side reference
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float sqrt_bc2 = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = lr / bc1, decay = 1.f - lr * wd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float pi = p[i] * decay;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);   // lerp_, as torch's single-tensor path
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+__global__ void step_inc_kernel(const float* norm_ws, int64_t* step_dev) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && norm_ws[0] < INFINITY) step_dev[0] += 1;
+}
+
+// packed[dst_off + (r*T + t)*Cpad + c] = bf16(flat[src_off + r1*s_r + r2*s_r2 + tt*s_t + c*s_c]) (0 for c >= C)
+__global__ __launch_bounds__(256) void pack_kernel(const float* flat, unsigned short* packed,
+                                                   const aau_pack_entry* table, int n_entries) {
+    // locate this block's entry (table is short: linear scan on the scalar unit)
+    int e = 0;
+    const int64_t blk = blockIdx.x;
+    while (e + 1 < n_entries && table[e + 1].blk_begin <= blk) ++e;
+    const aau_pack_entry ent = table[e];
+    const int64_t total = (int64_t)ent.R * ent.T * ent.Cpad;
+    const int64_t i = (blk - ent.blk_begin) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % ent.Cpad);
+    const int64_t rt = i / ent.Cpad;
+    const int t = (int)(rt % ent.T);
+    const int r = (int)(rt / ent.T);
+    float val = 0.f;
+    if (c < ent.C) {
+        const int tt = ent.t_flip ? ent.T - 1 - t : t;
+        int64_t off = ent.src_off + (int64_t)tt * ent.s_t + (int64_t)c * ent.s_c;
+        if (ent.R2 > 0) off += (int64_t)(r / ent.R2) * ent.s_r + (int64_t)(r % ent.R2) * ent.s_r2;
+        else off += (int64_t)r * ent.s_r;
+        val = flat[off];
+    }
+    packed[ent.dst_off + i] = f2bf(val);
+}
+
+}  // namespace aau
+
+using namespace aau;
+
+extern "C" int aau_grad_sqnorm(const float* grad, int64_t n, float inv_scale, float* norm_ws, void* stream) {
+    AAU_REQUIRE(grad && norm_ws && n > 0, "aau_grad_sqnorm: bad args");
+    AAU_REQUIRE(((uintptr_t)grad & 15) == 0, "aau_grad_sqnorm: grad must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(3, 0, s);
+    hipMemsetAsync(norm_ws, 0, sizeof(float), s);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grad, n, inv_scale, norm_ws);
+    return check_launch("aau_grad_sqnorm");
+}
+
+extern "C" int aau_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const float* norm_ws,
+                              int64_t* step_dev, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              float max_norm, float inv_scale, void* stream) {
+    AAU_REQUIRE(p && m && v && g && norm_ws && step_dev && n > 0, "aau_adamw_step: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(3, 0, s);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, m, v, g, n, norm_ws, step_dev, lr,
+                       beta1, beta2, eps, weight_decay, max_norm, inv_scale);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, norm_ws, step_dev);
+    return check_launch("aau_adamw_step");
+}
+
+extern "C" int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_pack_entry* table_dev,
+                                int n_entries, int64_t total_blocks, void* stream) {
+    AAU_REQUIRE(flat && packed && table_dev && n_entries > 0 && total_blocks > 0 && total_blocks < 0x7fffffff,
+                "aau_pack_weights: bad args");
+    ProfScope prof(3, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, flat, packed,
+                       table_dev, n_entries);
+    return check_launch("aau_pack_weights");
+}

@@ -1,0 +1,467 @@
+// Bandwidth-bound ends of the network that do not belong on MFMA:
+//   * the first convolution, Conv2d(1, C, 3, pad 1) on the fp32 frame (K = 9) and its
+//     weight gradient (pipeline:113, d1[0]);
+//   * out_conv, Conv2d(C, 1, 1) with bias (pipeline:122), forward and backward;
+//   * the ASPP image-pool branch reductions / broadcast (pipeline:75-77,82);
+//   * per-channel column sums (ConvTranspose2d bias gradient, pipeline:101);
+//   * layout / dtype plumbing at the module boundary and the TTA flip (pipeline:336-338).
+#include "common.h"
+
+namespace aau {
+
+struct CGMap2 {
+    int CG, PL, T;
+    __device__ __host__ explicit CGMap2(int C) {
+        CG = C >> 3;
+        PL = 256 / CG;
+        if (PL < 1) PL = 1;
+        T = CG * PL;
+    }
+};
+
+__device__ __forceinline__ void block_sum8b(float acc[8], float* red, const CGMap2& mp, int tid) {
+    __syncthreads();
+    if (tid < mp.T) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < mp.CG) {
+        for (int pl = 1; pl < mp.PL; ++pl) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += red[(pl * mp.CG + tid) * 8 + j];
+        }
+    }
+}
+
+// ---- first layer forward: z[m][c] = sum_t x[m+t] * w[c][t]; stats of z ----
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* x, const float* w, unsigned short* z,
+                                                        float* stats, int N, int H, int W, int C, int64_t ppb) {
+    extern __shared__ float sm[];  // [C*9] weights, then [256*8] reduction scratch
+    float* sw = sm;
+    float* sred = sm + C * 9;
+    for (int i = threadIdx.x; i < C * 9; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (tid < mp.T) {
+        const int64_t M = (int64_t)N * H * W;
+        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+            const int xx = (int)(m % W);
+            const int64_t t = m / W;
+            const int yy = (int)(t % H);
+            const float* img = x + (t - yy) * W;  // start of image n
+            float v[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+                    v[ky * 3 + kx] = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
+                                         ? img[(int64_t)y2 * W + x2] : 0.f;
+                }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc += v[k] * sw[(c + j) * 9 + k];
+                o[j] = acc;
+                s1[j] += acc;
+                s2[j] += acc * acc;
+            }
+            *(u32x4*)(z + m * C + c) = pack8(o);
+        }
+    }
+    if (stats) {
+        float* r = stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * C;
+        block_sum8b(s1, sred, mp, tid);
+        if (tid < mp.CG) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s1[j]);
+        }
+        block_sum8b(s2, sred, mp, tid);
+        if (tid < mp.CG) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
+        }
+    }
+}
+
+// ---- first layer weight gradient: dw[c][t] += sum_m dz[m][c] * x[m+t] ----
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* x, const unsigned short* dz, float* dw, int N,
+                                                          int H, int W, int C, int64_t ppb) {
+    extern __shared__ float sacc[];  // [C*9]
+    for (int i = threadIdx.x; i < C * 9; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    if (tid < mp.T) {
+        float acc[8][9];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[j][k] = 0.f;
+        const int64_t M = (int64_t)N * H * W;
+        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+            const int xx = (int)(m % W);
+            const int64_t t = m / W;
+            const int yy = (int)(t % H);
+            const float* img = x + (t - yy) * W;
+            float g[8];
+            unpack8(*(const u32x4*)(dz + m * C + c), g);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+                    const float v = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
+                                        ? img[(int64_t)y2 * W + x2] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j][ky * 3 + kx] += g[j] * v;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicAdd(&sacc[(c + j) * 9 + k], acc[j][k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(dw + i, sacc[i]);
+}
+
+// ---- out_conv forward: logits[m] = b + sum_c w[c]*y[m][c], one thread per pixel ----
+__global__ __launch_bounds__(256) void outconv_fwd_kernel(const unsigned short* y, int yp, const float* w,
+                                                          const float* b, float* logits, int64_t M, int C) {
+    extern __shared__ float sw[];
+    for (int i = threadIdx.x; i < C; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const float bias = b ? b[0] : 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+        float acc = bias;
+        for (int c = 0; c < C; c += 8) {
+            float f[8];
+            unpack8(*(const u32x4*)(y + m * yp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += f[j] * sw[c + j];
+        }
+        logits[m] = acc;
+    }
+}
+
+// ---- out_conv backward: dy = dl*w ; dw += sum dl*y ; db += sum dl ----
+__global__ __launch_bounds__(256) void outconv_bwd_kernel(const unsigned short* y, int yp, const float* dl,
+                                                          const float* w, unsigned short* dy, int dyp, float* dw,
+                                                          float* db, int64_t M, int C, int64_t ppb) {
+    __shared__ float sred[256 * 8];
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float s[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = sb[j] = 0.f;
+    if (tid < mp.T) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = w[c + j];
+        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+            const float g = dl[m];
+            float f[8], o[8];
+            unpack8(*(const u32x4*)(y + m * yp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += g * f[j]; o[j] = g * wv[j]; }
+            if (cg == 0) sb[0] += g;
+            *(u32x4*)(dy + m * dyp + c) = pack8(o);
+        }
+    }
+    block_sum8b(s, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(dw + c + j, s[j]);
+    }
+    block_sum8b(sb, sred, mp, tid);
+    if (tid == 0 && db) atomicAdd(db, sb[0]);
+}
+
+// ---- out[n][c] = alpha * sum_p src[n][p][c]; one block per (image, slab of pixels) ----
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const unsigned short* src, int sp, float* acc32, int HW,
+                                                          int C, int64_t ppb) {
+    __shared__ float sred[256 * 8];
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    const int n = blockIdx.y;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (tid < mp.T) {
+        const int64_t p0 = (int64_t)blockIdx.x * ppb, p1 = min((int64_t)HW, p0 + ppb);
+        for (int64_t p = p0 + pl; p < p1; p += mp.PL) {
+            float f[8];
+            unpack8(*(const u32x4*)(src + ((int64_t)n * HW + p) * sp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
+        }
+    }
+    block_sum8b(s, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(acc32 + (int64_t)n * C + c + j, s[j]);
+    }
+}
+
+__global__ void scale_to_bf16_kernel(const float* src, unsigned short* dst, int64_t n, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dst[i] = f2bf(src[i] * alpha);
+}
+
+// dx[n][p][c] += dpooled[n][c] * inv_hw
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const unsigned short* dpooled, unsigned short* dx, int dxp, int N,
+                                                      int HW, int C, float inv_hw) {
+    const int CG = C >> 3;
+    const int64_t total = (int64_t)N * HW * CG;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+        const int64_t m = v / CG;
+        const int c = (int)(v - m * CG) * 8;
+        const int n = (int)(m / HW);
+        float g[8], o[8];
+        unpack8(*(const u32x4*)(dpooled + (int64_t)n * C + c), g);
+        unpack8(*(const u32x4*)(dx + m * dxp + c), o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += g[j] * inv_hw;
+        *(u32x4*)(dx + m * dxp + c) = pack8(o);
+    }
+}
+
+// out[c] += sum_m src[m][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* src, int sp, float* out, int64_t M, int C,
+                                                     int64_t ppb) {
+    __shared__ float sred[256 * 8];
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (tid < mp.T) {
+        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+            float f[8];
+            unpack8(*(const u32x4*)(src + m * sp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
+        }
+    }
+    block_sum8b(s, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(out + c + j, s[j]);
+    }
+}
+
+// ---- plumbing ----
+__global__ void f32_to_bf16_kernel(const float* s, unsigned short* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = f2bf(s[i]);
+}
+__global__ void bf16_to_f32_kernel(const unsigned short* s, float* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = bf2f(s[i]);
+}
+__global__ void nchw_to_nhwc_kernel(const float* s, unsigned short* d, int dp, int N, int C, int H, int W) {
+    const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t m = i / C;
+        const int64_t n = m / HW, p = m - n * HW;
+        d[m * dp + c] = f2bf(s[(n * C + c) * HW + p]);
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const unsigned short* s, int sp, float* d, int N, int C, int H, int W) {
+    const int64_t HW = (int64_t)H * W, total = (int64_t)N * HW * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % HW;
+        const int64_t t = i / HW;
+        const int c = (int)(t % C);
+        const int64_t n = t / C;
+        d[i] = bf2f(s[(n * HW + p) * sp + c]);
+    }
+}
+__global__ void hflip_kernel(const float* s, float* d, int64_t rows, int W) {
+    const int64_t total = rows * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        d[i] = s[i - x + (W - 1 - x)];
+    }
+}
+__global__ void tta_merge_kernel(const float* l, const float* lf, float* prob, int64_t rows, int W) {
+    const int64_t total = rows * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        const float v = (l[i] + lf[i - x + (W - 1 - x)]) * 0.5f;
+        prob[i] = 1.f / (1.f + expf(-v));
+    }
+}
+
+static inline int grid1d(int64_t n, int cap = 4096) {
+    int64_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+static inline void split_rows(int64_t M, int PL, int min_iters, int max_blocks, int64_t* blocks, int64_t* ppb) {
+    int64_t b = (M + (int64_t)PL * min_iters - 1) / ((int64_t)PL * min_iters);
+    if (b > max_blocks) b = max_blocks;
+    if (b < 1) b = 1;
+    *ppb = (M + b - 1) / b;
+    *blocks = (M + *ppb - 1) / *ppb;
+}
+
+}  // namespace aau
+
+using namespace aau;
+
+#define CHK_C(fn, C) AAU_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) <= 2048, fn ": C=%d must be a multiple of 8 in [8, 2048]", (int)(C))
+
+extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, float* stats, int N, int H, int W, int C,
+                             void* stream) {
+    AAU_REQUIRE(x && w && z && N > 0 && H > 0 && W > 0, "aau_conv1_fwd: bad args");
+    CHK_C("aau_conv1_fwd", C);
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows((int64_t)N * H * W, mp.PL, 16, 4096, &blocks, &ppb);
+    ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), (C * 9 + 256 * 8) * sizeof(float),
+                       (hipStream_t)stream, x, w, z, stats, N, H, W, C, ppb);
+    return check_launch("aau_conv1_fwd");
+}
+
+extern "C" int aau_conv1_wgrad(const float* x, const aau_bf16* dz, float* dw, int N, int H, int W, int C,
+                               void* stream) {
+    AAU_REQUIRE(x && dz && dw && N > 0 && H > 0 && W > 0, "aau_conv1_wgrad: bad args");
+    CHK_C("aau_conv1_wgrad", C);
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows((int64_t)N * H * W, mp.PL, 32, 1024, &blocks, &ppb);
+    ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), C * 9 * sizeof(float),
+                       (hipStream_t)stream, x, dz, dw, N, H, W, C, ppb);
+    return check_launch("aau_conv1_wgrad");
+}
+
+extern "C" int aau_outconv_fwd(const aau_bf16* y, int y_pitch, const float* w, const float* b, float* logits,
+                               int64_t M, int C, void* stream) {
+    AAU_REQUIRE(y && w && logits && M > 0, "aau_outconv_fwd: bad args");
+    CHK_C("aau_outconv_fwd", C);
+    AAU_REQUIRE(y_pitch % 8 == 0, "aau_outconv_fwd: pitch");
+    ProfScope prof(2, 2.0 * M * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(outconv_fwd_kernel, dim3(grid1d(M)), dim3(256), C * sizeof(float), (hipStream_t)stream, y,
+                       y_pitch, w, b, logits, M, C);
+    return check_launch("aau_outconv_fwd");
+}
+
+extern "C" int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlogits, const float* w, aau_bf16* dy,
+                               int dy_pitch, float* dw, float* db, int64_t M, int C, void* stream) {
+    AAU_REQUIRE(y && dlogits && w && dy && dw && M > 0, "aau_outconv_bwd: bad args");
+    CHK_C("aau_outconv_bwd", C);
+    AAU_REQUIRE(y_pitch % 8 == 0 && dy_pitch % 8 == 0, "aau_outconv_bwd: pitch");
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows(M, mp.PL, 16, 2048, &blocks, &ppb);
+    ProfScope prof(2, 4.0 * M * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(outconv_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, y_pitch,
+                       dlogits, w, dy, dy_pitch, dw, db, M, C, ppb);
+    return check_launch("aau_outconv_bwd");
+}
+
+static int spatial_reduce(const aau_bf16* src, int sp, aau_bf16* out, int N, int HW, int C, float alpha,
+                          float* ws, hipStream_t s) {
+    const int64_t need = (int64_t)N * C;
+    hipMemsetAsync(ws, 0, need * sizeof(float), s);
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows(HW, mp.PL, 8, 64, &blocks, &ppb);
+    hipLaunchKernelGGL(spatial_sum_kernel, dim3((unsigned)blocks, N), dim3(256), 0, s, src, sp, ws, HW, C, ppb);
+    hipLaunchKernelGGL(scale_to_bf16_kernel, dim3(grid1d(need)), dim3(256), 0, s, ws, out, need, alpha);
+    return check_launch("spatial reduce");
+}
+
+extern "C" int aau_gap_fwd(const aau_bf16* x, int x_pitch, aau_bf16* pooled, float* ws, int N, int HW, int C,
+                           void* stream) {
+    AAU_REQUIRE(x && pooled && ws && N > 0 && HW > 0, "aau_gap_fwd: bad args");
+    CHK_C("aau_gap_fwd", C);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    return spatial_reduce(x, x_pitch, pooled, N, HW, C, 1.0f / (float)HW, ws, (hipStream_t)stream);
+}
+
+extern "C" int aau_spatial_sum(const aau_bf16* src, int src_pitch, aau_bf16* out, float* ws, int N, int HW, int C,
+                               void* stream) {
+    AAU_REQUIRE(src && out && ws && N > 0 && HW > 0, "aau_spatial_sum: bad args");
+    CHK_C("aau_spatial_sum", C);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    return spatial_reduce(src, src_pitch, out, N, HW, C, 1.0f, ws, (hipStream_t)stream);
+}
+
+extern "C" int aau_gap_bwd(const aau_bf16* dpooled, aau_bf16* dx, int dx_pitch, int N, int HW, int C, void* stream) {
+    AAU_REQUIRE(dpooled && dx && N > 0 && HW > 0, "aau_gap_bwd: bad args");
+    CHK_C("aau_gap_bwd", C);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid1d((int64_t)N * HW * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       dpooled, dx, dx_pitch, N, HW, C, 1.0f / (float)HW);
+    return check_launch("aau_gap_bwd");
+}
+
+extern "C" int aau_colsum(const aau_bf16* src, int src_pitch, float* out, int64_t M, int C, void* stream) {
+    AAU_REQUIRE(src && out && M > 0, "aau_colsum: bad args");
+    CHK_C("aau_colsum", C);
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows(M, mp.PL, 16, 1024, &blocks, &ppb);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, src_pitch, out,
+                       M, C, ppb);
+    return check_launch("aau_colsum");
+}
+
+extern "C" int aau_f32_to_bf16(const float* src, aau_bf16* dst, int64_t n, void* stream) {
+    AAU_REQUIRE(src && dst && n > 0, "aau_f32_to_bf16: bad args");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return check_launch("aau_f32_to_bf16");
+}
+extern "C" int aau_bf16_to_f32(const aau_bf16* src, float* dst, int64_t n, void* stream) {
+    AAU_REQUIRE(src && dst && n > 0, "aau_bf16_to_f32: bad args");
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return check_launch("aau_bf16_to_f32");
+}
+extern "C" int aau_nchw_to_nhwc(const float* src, aau_bf16* dst, int dst_pitch, int N, int C, int H, int W,
+                                void* stream) {
+    AAU_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && dst_pitch >= C, "aau_nchw_to_nhwc: bad args");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid1d((int64_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, dst_pitch, N, C, H, W);
+    return check_launch("aau_nchw_to_nhwc");
+}
+extern "C" int aau_nhwc_to_nchw(const aau_bf16* src, int src_pitch, float* dst, int N, int C, int H, int W,
+                                void* stream) {
+    AAU_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && src_pitch >= C, "aau_nhwc_to_nchw: bad args");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid1d((int64_t)N * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       src, src_pitch, dst, N, C, H, W);
+    return check_launch("aau_nhwc_to_nchw");
+}
+extern "C" int aau_hflip_f32(const float* src, float* dst, int N, int H, int W, void* stream) {
+    AAU_REQUIRE(src && dst && src != dst && N > 0 && H > 0 && W > 0, "aau_hflip_f32: bad args");
+    hipLaunchKernelGGL(hflip_kernel, dim3(grid1d((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (int64_t)N * H, W);
+    return check_launch("aau_hflip_f32");
+}
+extern "C" int aau_tta_merge(const float* l, const float* l_flipped, float* prob, int N, int H, int W, void* stream) {
+    AAU_REQUIRE(l && l_flipped && prob && N > 0 && H > 0 && W > 0, "aau_tta_merge: bad args");
+    hipLaunchKernelGGL(tta_merge_kernel, dim3(grid1d((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, l,
+                       l_flipped, prob, (int64_t)N * H, W);
+    return check_launch("aau_tta_merge");
+}

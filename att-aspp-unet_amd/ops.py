@@ -1,0 +1,201 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per entry point).
+
+Tensors are device memory handles only: every function extracts ``data_ptr()`` and the
+current HIP stream and calls into ``libaau.so``.  NHWC bf16 activations are passed as
+torch tensors of dtype bfloat16 whose last dimension is the channel dimension; a
+channel slice of a wider buffer is passed as (tensor view, pitch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import ConvDesc, PackEntry, STAT_REPLICAS, check, fn
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def pitch_of(t: torch.Tensor) -> int:
+    """Pixel pitch (elements) of an NHWC tensor/view whose last dim is contiguous."""
+    assert t.stride(-1) == 1, "channel dimension must be contiguous"
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def cpad_of(cin: int) -> int:
+    """Per-tap channel count of packed weights (the kernel steps K by 64 when this is a
+    multiple of 64, else by 32; channels past ``cin`` are zero)."""
+    return round_up(cin, 32)
+
+
+def conv_desc(N, H, W, Cin, src_pitch, Ho, Wo, Cout, dst_pitch, KH=1, KW=1, stride=1, pad=0, dil=1,
+              Cpad=None, shuffle2x2=0, accumulate=0, relu=0) -> ConvDesc:
+    if Cpad is None:
+        Cpad = cpad_of(Cin)
+    return ConvDesc(N, H, W, Cin, src_pitch, Ho, Wo, Cout, dst_pitch, KH, KW, stride, pad, dil, Cpad,
+                    shuffle2x2, accumulate, relu)
+
+
+def conv_igemm(desc: ConvDesc, src, wpk, dst, bias=None, scale=None, shift=None, stats=None):
+    check(fn("aau_conv_igemm")(C.byref(desc), _p(src), _p(wpk), _p(dst), _p(bias), _p(scale), _p(shift),
+                               _p(stats), _stream()), "aau_conv_igemm")
+
+
+def conv_wgrad(desc: ConvDesc, src, dz, dw):
+    check(fn("aau_conv_wgrad")(C.byref(desc), _p(src), _p(dz), _p(dw), _stream()), "aau_conv_wgrad")
+
+
+def conv1_fwd(x, w, z, stats, N, H, W, Cc):
+    check(fn("aau_conv1_fwd")(_p(x), _p(w), _p(z), _p(stats), N, H, W, Cc, _stream()), "aau_conv1_fwd")
+
+
+def conv1_wgrad(x, dz, dw, N, H, W, Cc):
+    check(fn("aau_conv1_wgrad")(_p(x), _p(dz), _p(dw), N, H, W, Cc, _stream()), "aau_conv1_wgrad")
+
+
+def pack_weights(flat, packed, table_dev, n_entries, total_blocks):
+    check(fn("aau_pack_weights")(_p(flat), _p(packed), _p(table_dev), n_entries, total_blocks, _stream()),
+          "aau_pack_weights")
+
+
+def bn_finalize(stats, gamma, beta, rmean, rvar, nbt, scale, shift, smean, sinvstd, Cc, count,
+                eps=1e-5, momentum=0.1):
+    check(fn("aau_bn_finalize")(_p(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(scale),
+                                _p(shift), _p(smean), _p(sinvstd), Cc, count, eps, momentum, _stream()),
+          "aau_bn_finalize")
+
+
+def bn_fold_eval(gamma, beta, rmean, rvar, scale, shift, Cc, eps=1e-5):
+    check(fn("aau_bn_fold_eval")(_p(gamma), _p(beta), _p(rmean), _p(rvar), _p(scale), _p(shift), Cc, eps,
+                                 _stream()), "aau_bn_fold_eval")
+
+
+def bn_act(z, zp, y, yp, scale, shift, M, Cc, relu=1, bcast_hw=0, drop_p=0.0, drop_seed=0):
+    check(fn("aau_bn_act")(_p(z), zp, _p(y), yp, _p(scale), _p(shift), M, Cc, relu, bcast_hw, drop_p,
+                           drop_seed, _stream()), "aau_bn_act")
+
+
+def maxpool2(y, yp, p, pp, N, H, W, Cc):
+    check(fn("aau_maxpool2")(_p(y), yp, _p(p), pp, N, H, W, Cc, _stream()), "aau_maxpool2")
+
+
+def bn_bwd_reduce(z, zp, dy, dyp, dpool, dpp, dz, dzp, scale, shift, smean, sinvstd, red, N, H, W, Cc,
+                  relu=1, drop_p=0.0, drop_seed=0):
+    check(fn("aau_bn_bwd_reduce")(_p(z), zp, _p(dy), dyp, _p(dpool), dpp, _p(dz), dzp, _p(scale), _p(shift),
+                                  _p(smean), _p(sinvstd), _p(red), N, H, W, Cc, relu, drop_p, drop_seed,
+                                  _stream()), "aau_bn_bwd_reduce")
+
+
+def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, Cc):
+    check(fn("aau_bn_bwd_apply")(_p(z), zp, _p(dz), dzp, _p(gamma), _p(smean), _p(sinvstd), _p(red),
+                                 _p(dgamma), _p(dbeta), M, Cc, _stream()), "aau_bn_bwd_apply")
+
+
+def gap_fwd(x, xp, pooled, ws, N, HW, Cc):
+    check(fn("aau_gap_fwd")(_p(x), xp, _p(pooled), _p(ws), N, HW, Cc, _stream()), "aau_gap_fwd")
+
+
+def gap_bwd(dpooled, dx, dxp, N, HW, Cc):
+    check(fn("aau_gap_bwd")(_p(dpooled), _p(dx), dxp, N, HW, Cc, _stream()), "aau_gap_bwd")
+
+
+def spatial_sum(src, sp, out, ws, N, HW, Cc):
+    check(fn("aau_spatial_sum")(_p(src), sp, _p(out), _p(ws), N, HW, Cc, _stream()), "aau_spatial_sum")
+
+
+def gate_psi(zg, zx, sg, hg, sx, hx, wpsi, psi_pre, stats, M, Fi):
+    check(fn("aau_gate_psi")(_p(zg), _p(zx), _p(sg), _p(hg), _p(sx), _p(hx), _p(wpsi), _p(psi_pre),
+                             _p(stats), M, Fi, _stream()), "aau_gate_psi")
+
+
+def gate_apply(x, xp, psi_pre, scale1, shift1, alpha, out, op, M, Cc):
+    check(fn("aau_gate_apply")(_p(x), xp, _p(psi_pre), _p(scale1), _p(shift1), _p(alpha), _p(out), op, M, Cc,
+                               _stream()), "aau_gate_apply")
+
+
+def gate_bwd1(dout, dop, x, xp, alpha, psi_pre, mean1, invstd1, dx, dxp, dq, red1, M, Cc):
+    check(fn("aau_gate_bwd1")(_p(dout), dop, _p(x), xp, _p(alpha), _p(psi_pre), _p(mean1), _p(invstd1),
+                              _p(dx), dxp, _p(dq), _p(red1), M, Cc, _stream()), "aau_gate_bwd1")
+
+
+def gate_bwd2(dq, psi_pre, red1, gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x,
+              invstd_x, wpsi, ds, dwpsi, redg, redx, dgamma1, dbeta1, M, Fi):
+    args = [dq, psi_pre, red1, gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x,
+            invstd_x, wpsi, ds, dwpsi, redg, redx, dgamma1, dbeta1]
+    check(fn("aau_gate_bwd2")(*[_p(a) for a in args], M, Fi, _stream()), "aau_gate_bwd2")
+
+
+def gate_bwd3(ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x, redx, dzg, dzx,
+              dgamma_g, dbeta_g, dgamma_x, dbeta_x, M, Fi):
+    args = [ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x, redx, dzg, dzx,
+            dgamma_g, dbeta_g, dgamma_x, dbeta_x]
+    check(fn("aau_gate_bwd3")(*[_p(a) for a in args], M, Fi, _stream()), "aau_gate_bwd3")
+
+
+def outconv_fwd(y, yp, w, b, logits, M, Cc):
+    check(fn("aau_outconv_fwd")(_p(y), yp, _p(w), _p(b), _p(logits), M, Cc, _stream()), "aau_outconv_fwd")
+
+
+def outconv_bwd(y, yp, dlogits, w, dy, dyp, dw, db, M, Cc):
+    check(fn("aau_outconv_bwd")(_p(y), yp, _p(dlogits), _p(w), _p(dy), dyp, _p(dw), _p(db), M, Cc, _stream()),
+          "aau_outconv_bwd")
+
+
+def colsum(src, sp, out, M, Cc):
+    check(fn("aau_colsum")(_p(src), sp, _p(out), M, Cc, _stream()), "aau_colsum")
+
+
+def criterion(logits, targets, sums, loss_out, dlogits, B, H, W, finetune=False, neg_bce_w=0.05, edge_w=0.05,
+              loss_scale=1.0):
+    check(fn("aau_criterion")(_p(logits), _p(targets), _p(sums), _p(loss_out), _p(dlogits), B, H, W,
+                              1 if finetune else 0, neg_bce_w, edge_w, loss_scale, _stream()), "aau_criterion")
+
+
+def seg_metrics(logits, targets, sums, out, B, H, W, thr=0.5):
+    check(fn("aau_seg_metrics")(_p(logits), _p(targets), _p(sums), _p(out), B, H, W, thr, _stream()),
+          "aau_seg_metrics")
+
+
+def grad_sqnorm(grad, n, inv_scale, ws):
+    check(fn("aau_grad_sqnorm")(_p(grad), n, inv_scale, _p(ws), _stream()), "aau_grad_sqnorm")
+
+
+def adamw_step(p, m, v, g, n, norm_ws, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4,
+               max_norm=1.0, inv_scale=1.0):
+    check(fn("aau_adamw_step")(_p(p), _p(m), _p(v), _p(g), n, _p(norm_ws), _p(step_dev), lr, beta1, beta2, eps,
+                               weight_decay, max_norm, inv_scale, _stream()), "aau_adamw_step")
+
+
+def f32_to_bf16(src, dst, n):
+    check(fn("aau_f32_to_bf16")(_p(src), _p(dst), n, _stream()), "aau_f32_to_bf16")
+
+
+def bf16_to_f32(src, dst, n):
+    check(fn("aau_bf16_to_f32")(_p(src), _p(dst), n, _stream()), "aau_bf16_to_f32")
+
+
+def nchw_to_nhwc(src, dst, dst_pitch, N, Cc, H, W):
+    check(fn("aau_nchw_to_nhwc")(_p(src), _p(dst), dst_pitch, N, Cc, H, W, _stream()), "aau_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, src_pitch, dst, N, Cc, H, W):
+    check(fn("aau_nhwc_to_nchw")(_p(src), src_pitch, _p(dst), N, Cc, H, W, _stream()), "aau_nhwc_to_nchw")
+
+
+def hflip_f32(src, dst, N, H, W):
+    check(fn("aau_hflip_f32")(_p(src), _p(dst), N, H, W, _stream()), "aau_hflip_f32")
+
+
+def tta_merge(l, lf, prob, N, H, W):
+    check(fn("aau_tta_merge")(_p(l), _p(lf), _p(prob), N, H, W, _stream()), "aau_tta_merge")

@@ -1,0 +1,241 @@
+/*
+ * aau.h -- C ABI of the MI355X (gfx950) Attention-ASPP-UNet hot-path library.
+ *
+ * The reference (vivi-git188/ATT-ASPP-UNET) is pure Python on PyTorch: it has no FFI
+ * of its own, its "operator interface" for this path is the nn.Module / function
+ * surface of attention_aspp_unet_pipeline_stage.py (abbreviated "pipeline" below).
+ * Every entry point here names the reference call site whose arithmetic it replaces.
+ * The host side (the *.py files of att-aspp-unet_amd/) mirrors that Python surface and reaches this
+ * library through ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  Device pointers unless stated.
+ *   - activations: NHWC, bf16 ("u16" bit patterns), a pixel's channels contiguous;
+ *     every tensor argument carries a pixel pitch (elements between two pixels) so a
+ *     channel slice of a wider concat buffer is addressable without a copy.
+ *   - parameters / gradients / statistics: fp32.  Conv weights are physically
+ *     [Cout][KH][KW][Cin] (the channels_last image of PyTorch's OIHW tensor);
+ *     ConvTranspose2d weights physically [Cin][KH][KW][Cout] (channels_last of IOHW).
+ *   - ownership: the caller owns every buffer; the library never allocates, frees or
+ *     keeps a pointer after the call returns.  No call synchronises the host: all
+ *     work is enqueued on `stream` (a hipStream_t passed as void*), so every entry
+ *     point is hipGraph-capturable.
+ *   - return value: 0 on success, negative on error (AAU_E_*); aau_last_error()
+ *     returns a thread-local message.  Nothing throws across the ABI.
+ *   - threading: re-entrant; safe to call from the autograd worker thread.
+ */
+#ifndef AAU_H_
+#define AAU_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AAU_OK 0
+#define AAU_E_INVALID (-1)     /* bad argument / unsupported shape */
+#define AAU_E_HIP (-2)         /* HIP runtime error at launch */
+
+#define AAU_STAT_REPLICAS 32   /* BN statistic accumulators are [REPLICAS][2][C] fp32 */
+
+typedef uint16_t aau_bf16;
+
+const char* aau_last_error(void);
+int aau_version(void);
+
+/* ---- launch profiling (used by bench.py for the live roofline figure) ------------- */
+/* While enabled every kernel launch is bracketed by hipEvents on its own stream.      */
+/* families: 0 igemm (fwd+dgrad), 1 wgrad, 2 elementwise/reduction, 3 optimizer+loss   */
+#define AAU_PROF_FAMILIES 4
+int aau_prof_enable(int on);
+/* Synchronises the recorded events (host sync: never call inside graph capture),     */
+/* returns per-family summed kernel time [ms], launch counts and algorithmic FLOPs,   */
+/* then clears the records.                                                           */
+int aau_prof_collect(double ms[AAU_PROF_FAMILIES], int64_t launches[AAU_PROF_FAMILIES],
+                     double flops[AAU_PROF_FAMILIES]);
+
+/* ---- implicit-GEMM convolution on MFMA --------------------------------------------- */
+/* One descriptor drives forward convolution (pipeline:63 Conv2d in ConvBNReLU, :71-78  */
+/* ASPP convs incl. dilation, :88-90 gate 1x1, :101 ConvTranspose2d as a 1x1 GEMM with a */
+/* pixel-shuffle store) and data-gradient convolution (the ATen convolution_backward    */
+/* input-gradient of the same call sites).                                              */
+typedef struct aau_conv_desc {
+    int32_t N, H, W;        /* gather-source spatial dims                               */
+    int32_t Cin;            /* channels read per tap (multiple of 8)                    */
+    int32_t src_pitch;      /* elements between source pixels                           */
+    int32_t Ho, Wo;         /* output grid; GEMM M = N*Ho*Wo                            */
+    int32_t Cout;           /* GEMM N (multiple of 8); for shuffle2x2 this is 4*Co      */
+    int32_t dst_pitch;      /* elements between destination pixels                      */
+    int32_t KH, KW;         /* taps                                                     */
+    int32_t stride, pad, dil;
+    int32_t Cpad;           /* per-tap channel count of the packed weights (mult. of 32) */
+    int32_t shuffle2x2;     /* 1: Cout = 4*Co ordered [dy][dx][co]; pixel (y,x) of the  */
+                            /*    GEMM writes destination pixel (2y+dy, 2x+dx), co      */
+    int32_t accumulate;     /* 1: dst += result (read-modify-write, bf16)               */
+    int32_t relu;           /* 1: clamp at 0 after the affine epilogue                  */
+} aau_conv_desc;
+
+/* dst[m][q] = epi( sum_{t,c} src[gather(m,t)][c] * wpk[q][t][c] )                      */
+/* wpk: bf16 [Cout][KH*KW][Cpad]; bias/scale/shift: optional fp32 [Cout] (NULL = none); */
+/* epi(v) = relu?( (v + bias) * scale + shift ).  stats (optional):                     */
+/* fp32 [AAU_STAT_REPLICAS][2][Cout], accumulates sum and sum of squares of v (pre-     */
+/* epilogue accumulator) per output channel -- the batch statistics of the following    */
+/* BatchNorm2d in training mode.  The caller zeroes stats beforehand.                   */
+int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
+                   aau_bf16* dst, const float* bias, const float* scale, const float* shift,
+                   float* stats, void* stream);
+
+/* Weight-gradient of the same convolutions (ATen convolution_backward, weight part):   */
+/* dw[q][t][c] += sum_m dz[m][q] * src[gather(m,t)][c]   (fp32 atomics; caller zeroes)   */
+/* d->Cout = channels of dz (pitch d->dst_pitch), d->Cin = channels of src.             */
+/* dw is [Cout][KH*KW][Cin] fp32 dense.  ConvTranspose2d(2,2) uses the same entry with    */
+/* the roles swapped by the caller: dz := the layer input g (q = its Cin), src := the      */
+/* output gradient gathered with stride 2 / 2x2 taps (c = Cout), giving [Cin][4][Cout].    */
+int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz,
+                   float* dw, void* stream);
+
+/* ---- first layer: Conv2d(1, C, 3, pad 1) on fp32 input (pipeline:113 d1[0]) --------- */
+int aau_conv1_fwd(const float* x, const float* w /*[C][9]*/, aau_bf16* z, float* stats,
+                  int N, int H, int W, int C, void* stream);
+int aau_conv1_wgrad(const float* x, const aau_bf16* dz, float* dw /*[C][9]*/,
+                    int N, int H, int W, int C, void* stream);
+
+/* ---- weight packing (fp32 master -> bf16 GEMM operands), table driven ---------------- */
+typedef struct aau_pack_entry {
+    int64_t src_off;        /* element offset into the flat fp32 parameter buffer        */
+    int64_t dst_off;        /* element offset into the packed bf16 buffer                */
+    int32_t R;              /* rows of the packed matrix                                 */
+    int32_t T;              /* taps                                                      */
+    int32_t C;              /* channels per tap                                          */
+    int32_t Cpad;           /* padded channels per tap in the packed matrix              */
+    int32_t s_r, s_t, s_c;  /* source strides (elements) of row / tap / channel          */
+    int32_t t_flip;         /* 1: packed tap t reads source tap T-1-t                    */
+    int32_t R2;             /* 0, or: row r = r1*R2 + r2 with strides (s_r, s_r2)        */
+    int32_t s_r2;
+    int64_t blk_begin;      /* first thread block of this entry (prefix sum)             */
+} aau_pack_entry;
+int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_pack_entry* table_dev,
+                     int n_entries, int64_t total_blocks, void* stream);
+
+/* ---- BatchNorm2d (pipeline:64 and every BN of :71-90) -------------------------------- */
+/* training: stats replicas -> mean / biased var -> scale = g*invstd, shift = b-mean*scale; */
+/* saves mean, invstd; running stats: momentum 0.1, unbiased var; nbt += 1.              */
+int aau_bn_finalize(const float* stats, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* scale, float* shift, float* save_mean, float* save_invstd,
+                    int C, int64_t count, float eps, float momentum, void* stream);
+/* eval: scale/shift from running statistics                                             */
+int aau_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float* scale, float* shift, int C, float eps,
+                     void* stream);
+/* y = relu?(z*scale+shift) [* dropout keep mask / (1-p)], optional broadcast of one     */
+/* source row per image (ASPP image-pool branch, pipeline:82).                           */
+int aau_bn_act(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pitch, const float* scale,
+               const float* shift, int64_t M, int C, int relu, int64_t bcast_hw,
+               float drop_p, uint64_t drop_seed, void* stream);
+/* MaxPool2d(2) (pipeline:115-118)                                                        */
+int aau_maxpool2(const aau_bf16* y, int y_pitch, aau_bf16* p, int p_pitch, int N, int H, int W,
+                 int C, void* stream);
+/* backward of [BN -> ReLU (-> dropout)] with up to two gradient sources:                 */
+/*   dy (same resolution, optional) and dpool (gradient of MaxPool2d(2) output, optional, */
+/*   routed to the first maximum of each window).  Pass 1 writes the masked gradient      */
+/*   g = relu'(y) * (dy + pool-routed) into dz and accumulates sum(g), sum(g*zhat) into    */
+/*   red [AAU_STAT_REPLICAS][2][C]; pass 2 turns it into dz in place and adds dgamma /     */
+/*   dbeta.                                                                              */
+int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16* dy, int dy_pitch,
+                      const aau_bf16* dpool, int dpool_pitch, aau_bf16* dz, int dz_pitch,
+                      const float* scale, const float* shift, const float* save_mean,
+                      const float* save_invstd, float* red, int N, int H, int W, int C,
+                      int relu, float drop_p, uint64_t drop_seed, void* stream);
+int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
+                     const float* gamma, const float* save_mean, const float* save_invstd,
+                     const float* red, float* dgamma, float* dbeta, int64_t M, int C,
+                     void* stream);
+
+/* ---- ASPP image-pool branch (pipeline:75-77,82) -------------------------------------- */
+/* ws: caller-provided fp32 [N*C] workspace (zeroed by the call)                        */
+int aau_gap_fwd(const aau_bf16* x, int x_pitch, aau_bf16* pooled, float* ws, int N, int HW, int C, void* stream);
+/* dsrc[n][p][c] += dpooled[n][c] / HW  (accumulate into bf16)                           */
+int aau_gap_bwd(const aau_bf16* dpooled, aau_bf16* dx, int dx_pitch, int N, int HW, int C, void* stream);
+/* out[n][c] = sum_p src[n][p][c]   (bf16 in, bf16 out, fp32 accumulate)                  */
+int aau_spatial_sum(const aau_bf16* src, int src_pitch, aau_bf16* out, float* ws, int N, int HW, int C, void* stream);
+
+/* ---- attention gate (pipeline:85-92) -------------------------------------------------- */
+/* psi_pre[m] = sum_f wpsi[f]*relu(zg[m,f]*sg[f]+hg[f] + zx[m,f]*sx[f]+hx[f]); also sum /   */
+/* sumsq of psi_pre into stats [REPLICAS][2][1].                                           */
+int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float* sg, const float* hg,
+                 const float* sx, const float* hx, const float* wpsi, float* psi_pre,
+                 float* stats, int64_t M, int F, void* stream);
+/* alpha[m] = sigmoid(psi_pre*scale1+shift1); out[m,c] = x[m,c]*alpha[m]                   */
+int aau_gate_apply(const aau_bf16* x, int x_pitch, const float* psi_pre, const float* scale1,
+                   const float* shift1, float* alpha, aau_bf16* out, int out_pitch, int64_t M,
+                   int C, void* stream);
+/* backward step 1: dx[m,c] = dout*alpha; dq[m] = (sum_c dout*x) * alpha*(1-alpha);          */
+/* red1 [REPLICAS][2][1] += (dq, dq*psihat)                                                */
+int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x_pitch,
+                  const float* alpha, const float* psi_pre, const float* mean1,
+                  const float* invstd1, aau_bf16* dx, int dx_pitch, float* dq, float* red1,
+                  int64_t M, int C, void* stream);
+/* backward step 2: dpsi_pre = BN(1) backward of dq; ds[m,f] = dpsi_pre*wpsi[f]*[s>0];      */
+/* writes ds (bf16, masked gradient shared by both branches), dwpsi[f] += sum dpsi_pre*s,   */
+/* redg/redx [REPLICAS][2][F] += (ds, ds*zhat_g) / (ds, ds*zhat_x); dgamma1/dbeta1.         */
+int aau_gate_bwd2(const float* dq, const float* psi_pre, const float* red1, const float* gamma1,
+                  const float* mean1, const float* invstd1, const aau_bf16* zg,
+                  const aau_bf16* zx, const float* sg, const float* hg, const float* sx,
+                  const float* hx, const float* mean_g, const float* invstd_g,
+                  const float* mean_x, const float* invstd_x, const float* wpsi,
+                  aau_bf16* ds, float* dwpsi, float* redg, float* redx, float* dgamma1,
+                  float* dbeta1, int64_t M, int F, void* stream);
+/* backward step 3: dzg/dzx from ds (BN backward without ReLU for both branches)            */
+int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_bf16* zx,
+                  const float* gamma_g, const float* mean_g, const float* invstd_g,
+                  const float* redg, const float* gamma_x, const float* mean_x,
+                  const float* invstd_x, const float* redx, aau_bf16* dzg, aau_bf16* dzx,
+                  float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x,
+                  int64_t M, int F, void* stream);
+
+/* ---- out_conv: Conv2d(C, 1, 1) with bias (pipeline:122) -------------------------------- */
+int aau_outconv_fwd(const aau_bf16* y, int y_pitch, const float* w, const float* b,
+                    float* logits, int64_t M, int C, void* stream);
+int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlogits, const float* w,
+                    aau_bf16* dy, int dy_pitch, float* dw, float* db, int64_t M, int C,
+                    void* stream);
+/* per-channel sum over pixels of a bf16 tensor into fp32 (ConvTranspose2d bias gradient)   */
+int aau_colsum(const aau_bf16* src, int src_pitch, float* out, int64_t M, int C, void* stream);
+
+/* ---- criterion (pipeline:219-232 build_criterion with ComboLoss :187-189, DiceLoss        */
+/* :173-178, EdgeLoss :196-216) and metrics (:191-194 iou_score, :240 eval Dice) -------- */
+/* sums: fp32 [B][8] workspace (zeroed by the call); loss_out: fp32 [4] = total, dice,      */
+/* bce, edge.  dlogits (optional, fp32 [B*H*W]) receives d(loss*loss_scale)/d(logits).       */
+int aau_criterion(const float* logits, const float* targets, float* sums, float* loss_out,
+                  float* dlogits, int B, int H, int W, int finetune, float neg_bce_w,
+                  float edge_w, float loss_scale, void* stream);
+/* metrics_out: fp32 [2] = mean soft Dice (1 - DiceLoss), mean hard IoU at thr            */
+int aau_seg_metrics(const float* logits, const float* targets, float* sums, float* metrics_out,
+                    int B, int H, int W, float thr, void* stream);
+
+/* ---- optimiser (pipeline:302 AdamW, :323 clip_grad_norm_) ------------------------------ */
+/* norm_ws: fp32 [1] zeroed by the call; accumulates sum of squares of grad*inv_scale       */
+int aau_grad_sqnorm(const float* grad, int64_t n, float inv_scale, float* norm_ws, void* stream);
+/* p,m,v,g: flat fp32 [n].  clip coefficient = min(1, max_norm/(sqrt(norm_ws)+1e-6));       */
+/* step_dev: int64 step counter on the device, incremented by the call (bias correction).  */
+/* If sqrt(norm_ws) is inf/nan the update is skipped (GradScaler semantics, :324).          */
+int aau_adamw_step(float* p, float* m, float* v, const float* g, int64_t n,
+                   const float* norm_ws, int64_t* step_dev, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float max_norm, float inv_scale, void* stream);
+
+/* ---- small utilities -------------------------------------------------------------------- */
+int aau_f32_to_bf16(const float* src, aau_bf16* dst, int64_t n, void* stream);
+int aau_bf16_to_f32(const aau_bf16* src, float* dst, int64_t n, void* stream);
+/* NCHW fp32 -> NHWC bf16 with pitch, and back (module-boundary plumbing)                   */
+int aau_nchw_to_nhwc(const float* src, aau_bf16* dst, int dst_pitch, int N, int C, int H, int W, void* stream);
+int aau_nhwc_to_nchw(const aau_bf16* src, int src_pitch, float* dst, int N, int C, int H, int W, void* stream);
+/* horizontal flip of [N][H][W] fp32 frames (TTA, pipeline:336-338) and the TTA merge        */
+int aau_hflip_f32(const float* src, float* dst, int N, int H, int W, void* stream);
+int aau_tta_merge(const float* l, const float* l_flipped, float* prob, int N, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AAU_H_ */

@@ -1,0 +1,39 @@
+"""CPU-side checks of the C ABI: the library loads without a GPU and exports every
+symbol that include/aau.h declares (no compute calls here)."""
+import ctypes
+import os
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol():
+    from att_aspp_unet_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = _abi.lib()
+    names = _abi.declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/aau.h but not exported"
+    assert lib.aau_version() >= 1
+    # every bound signature belongs to a declared symbol
+    assert set(_abi._SIGS) <= set(names)
+
+
+def test_struct_layouts_match_header():
+    from att_aspp_unet_amd import _abi
+    assert ctypes.sizeof(_abi.ConvDesc) == 18 * 4
+    assert ctypes.sizeof(_abi.PackEntry) == 8 + 8 + 10 * 4 + 8
+
+
+def test_invalid_arguments_fail_loudly_without_gpu():
+    from att_aspp_unet_amd import _abi
+    lib = _abi.lib()
+    d = _abi.ConvDesc()
+    d.Cin = 7  # not a multiple of 8
+    rc = lib.aau_conv_igemm(ctypes.byref(d), 16, 16, 16, None, None, None, None, None)
+    assert rc == -1
+    assert b"Cin" in lib.aau_last_error()
+    with pytest.raises(_abi.AauError):
+        _abi.check(rc, "aau_conv_igemm")

@@ -1,0 +1,181 @@
+"""GPU parity of single HIP kernels (through the C ABI) against CPU fp32 references.
+
+Inputs are rounded to bf16 first, so the only differences left are the fp32
+accumulation order and the final bf16 store (relative 2^-9 per element).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kernels_ref as R
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from att_aspp_unet_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def pack_fwd(w_oihw, cpad):
+    """[O][I][kh][kw] fp32 -> bf16 [O][T][Cpad] (what aau_pack_weights produces for the forward GEMM)."""
+    O, I, kh, kw = w_oihw.shape
+    out = torch.zeros(O, kh * kw, cpad)
+    out[:, :, :I] = w_oihw.permute(0, 2, 3, 1).reshape(O, kh * kw, I)
+    return out.to(torch.bfloat16)
+
+
+def pack_dgrad(w_oihw, cpad):
+    """-> bf16 [I][T flipped][Cpad(O)]"""
+    O, I, kh, kw = w_oihw.shape
+    out = torch.zeros(I, kh * kw, cpad)
+    out[:, :, :O] = w_oihw.flip(2, 3).permute(1, 2, 3, 0).reshape(I, kh * kw, O)
+    return out.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, dil
+    (2, 16, 16, 48, 48, 3, 1),
+    (1, 24, 40, 96, 96, 3, 1),
+    (2, 32, 32, 64, 128, 3, 6),
+    (2, 8, 8, 192, 96, 1, 1),
+    (1, 16, 16, 8, 16, 3, 1),
+    (1, 32, 32, 128, 200, 3, 18),
+    (3, 12, 20, 104, 56, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_igemm_forward_and_stats(ops, case):
+    N, H, W, Cin, Cout, k, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
+    w = R.bf16_round(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    ref = R.conv_fwd(x, w, dil)
+    cpad = ops.cpad_of(Cin)
+    d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, dil * (k // 2), dil, cpad)
+    xd, wd = dev(x.to(torch.bfloat16)), dev(pack_fwd(w, cpad))
+    out = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    ops.conv_igemm(d, xd, wd, out, stats=stats)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 6e-3
+    s = stats.sum(0).cpu()
+    flat = ref.reshape(-1, Cout)
+    assert float((s[0] - flat.sum(0)).abs().max()) < 2e-3 * float(flat.abs().sum(0).max())
+    assert torch.allclose(s[1], (flat ** 2).sum(0), rtol=2e-3)
+
+
+def test_igemm_epilogue_bias_affine_relu_accumulate_pitch(ops):
+    N, H, W, Cin, Cout = 2, 8, 8, 32, 48
+    g = torch.Generator().manual_seed(5)
+    xw = R.bf16_round(torch.randn(N, H, W, Cin + 16, generator=g))  # source = channel slice [8:40] of a wider tensor
+    x = xw[..., 8:8 + Cin]
+    w = R.bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5)
+    bias, scale, shift = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    prev = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    ref = torch.relu((R.conv_fwd(x, w) + bias) * scale + shift + prev)
+    cpad = ops.cpad_of(Cin)
+    xd = dev(xw.to(torch.bfloat16))
+    wide = torch.zeros(N, H, W, Cout + 24, dtype=torch.bfloat16, device="cuda")
+    wide[..., 16:16 + Cout] = dev(prev.to(torch.bfloat16))
+    d = ops.conv_desc(N, H, W, Cin, Cin + 16, H, W, Cout, Cout + 24, Cpad=cpad, accumulate=1, relu=1)
+    ops.conv_igemm(d, xd[..., 8:], dev(pack_fwd(w, cpad)), wide[..., 16:], bias=dev(bias), scale=dev(scale), shift=dev(shift))
+    torch.cuda.synchronize()
+    got = wide.cpu()
+    assert rel_err(got[..., 16:16 + Cout], ref) < 8e-3
+    assert float(got[..., :16].abs().max()) == 0 and float(got[..., 16 + Cout:].abs().max()) == 0  # neighbours untouched
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 48, 48, 3, 1), (1, 32, 32, 64, 96, 3, 6), (2, 8, 8, 96, 192, 1, 1)])
+def test_igemm_dgrad(ops, case):
+    N, H, W, Cin, Cout, k, dil = case
+    g = torch.Generator().manual_seed(17)
+    dy = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    w = R.bf16_round(torch.randn(Cout, Cin, k, k, generator=g) / (Cout * k * k) ** 0.5)
+    ref = R.conv_dgrad(dy, w, (H, W), dil)
+    cpad = ops.cpad_of(Cout)
+    d = ops.conv_desc(N, H, W, Cout, Cout, H, W, Cin, Cin, k, k, 1, dil * (k // 2), dil, cpad)
+    out = torch.empty(N, H, W, Cin, dtype=torch.bfloat16, device="cuda")
+    ops.conv_igemm(d, dev(dy.to(torch.bfloat16)), dev(pack_dgrad(w, cpad)), out)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 6e-3
+
+
+def test_convT_forward_shuffle_and_dgrad(ops):
+    N, H, W, Ci, Co = 2, 8, 12, 64, 32
+    g = torch.Generator().manual_seed(23)
+    x = R.bf16_round(torch.randn(N, H, W, Ci, generator=g))
+    w = R.bf16_round(torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5)  # IOHW
+    b = torch.randn(Co, generator=g)
+    ref = R.convT_fwd(x, w, b)
+    cpad = ops.cpad_of(Ci)
+    wp = torch.zeros(4 * Co, 1, cpad)  # forward GEMM rows: (pos, co) x cin
+    wp[:, 0, :Ci] = w.permute(2, 3, 1, 0).reshape(4 * Co, Ci)
+    d = ops.conv_desc(N, H, W, Ci, Ci, H, W, 4 * Co, Co + 8, Cpad=cpad, shuffle2x2=1)
+    wide = torch.zeros(N, 2 * H, 2 * W, Co + 8, dtype=torch.bfloat16, device="cuda")
+    ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(wp.to(torch.bfloat16)), wide[..., 8:], bias=dev(b.repeat(4)))
+    torch.cuda.synchronize()
+    assert rel_err(wide.cpu()[..., 8:], ref) < 6e-3
+    # data gradient: stride-2 2x2 gather of dy, rows = cin, K = (pos, co)
+    dy = R.bf16_round(torch.randn(N, 2 * H, 2 * W, Co, generator=g))
+    refd = R.convT_dgrad(dy, w)
+    cpd = ops.cpad_of(Co)
+    wdg = torch.zeros(Ci, 4, cpd)
+    wdg[:, :, :Co] = w.permute(0, 2, 3, 1).reshape(Ci, 4, Co)
+    dd = ops.conv_desc(N, 2 * H, 2 * W, Co, Co, H, W, Ci, Ci, 2, 2, 2, 0, 1, cpd)
+    out = torch.empty(N, H, W, Ci, dtype=torch.bfloat16, device="cuda")
+    ops.conv_igemm(dd, dev(dy.to(torch.bfloat16)), dev(wdg.to(torch.bfloat16)), out)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), refd) < 6e-3
+
+
+WGRAD_CASES = [
+    (2, 16, 16, 48, 48, 3, 1),
+    (1, 24, 40, 96, 48, 3, 1),
+    (2, 16, 16, 48, 96, 3, 1),
+    (2, 32, 32, 96, 192, 3, 6),
+    (2, 8, 8, 192, 96, 1, 1),
+    (1, 16, 16, 8, 16, 3, 1),
+    (3, 12, 20, 104, 56, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad(ops, case):
+    N, H, W, Cin, Cout, k, dil = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
+    dy = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    ref = R.conv_wgrad(x, dy, (Cout, Cin, k, k), dil)  # OIHW
+    d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, dil * (k // 2), dil)
+    dw = torch.zeros(Cout, k * k, Cin, device="cuda")
+    ops.conv_wgrad(d, dev(x.to(torch.bfloat16)), dev(dy.to(torch.bfloat16)), dw)
+    torch.cuda.synchronize()
+    got = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 2e-3
+
+
+def test_wgrad_convT(ops):
+    N, H, W, Ci, Co = 2, 8, 12, 64, 32
+    g = torch.Generator().manual_seed(29)
+    x = R.bf16_round(torch.randn(N, H, W, Ci, generator=g))
+    dy = R.bf16_round(torch.randn(N, 2 * H, 2 * W, Co, generator=g))
+    w = torch.zeros(Ci, Co, 2, 2)
+    ref = R.convT_wgrad(x, dy, w)  # [Ci][Co][2][2]
+    d = ops.conv_desc(N, 2 * H, 2 * W, Co, Co, H, W, Ci, Ci, 2, 2, 2, 0, 1)
+    dw = torch.zeros(Ci, 4, Co, device="cuda")
+    ops.conv_wgrad(d, dev(dy.to(torch.bfloat16)), dev(x.to(torch.bfloat16)), dw)
+    torch.cuda.synchronize()
+    got = dw.cpu().reshape(Ci, 2, 2, Co).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 2e-3
