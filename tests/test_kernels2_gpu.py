@@ -1,0 +1,341 @@
+"""GPU parity of the bandwidth-bound kernels (BN / pool / gate / loss / optimiser / packing)
+against CPU fp32 references and the reference-generated golden vectors."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kernels_ref as R
+from oracle import ref_cpu as O
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from att_aspp_unet_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+def zeros(*s, dtype=torch.float32):
+    return torch.zeros(*s, dtype=dtype, device="cuda")
+
+
+def test_conv1_bn_relu_chain_and_running_stats(ops):
+    N, H, W, C = 2, 24, 40, 48
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(N, 1, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    conv = F.conv2d(x, w, padding=1)
+    bn = torch.nn.BatchNorm2d(C)
+    bn.weight.data.copy_(gamma); bn.bias.data.copy_(beta)
+    bn.train()
+    ref = torch.relu(bn(conv)).permute(0, 2, 3, 1)
+    z = zeros(N, H, W, C, dtype=torch.bfloat16)
+    stats = zeros(ops.STAT_REPLICAS, 2, C)
+    ops.conv1_fwd(dev(x), dev(w.reshape(C, 9).contiguous()), z, stats, N, H, W, C)
+    scale, shift, sm, si = zeros(C), zeros(C), zeros(C), zeros(C)
+    rm, rv, nbt = zeros(C), torch.ones(C, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.bn_finalize(stats, dev(gamma), dev(beta), rm, rv, nbt, scale, shift, sm, si, C, N * H * W)
+    y = zeros(N, H, W, C, dtype=torch.bfloat16)
+    ops.bn_act(z, C, y, C, scale, shift, N * H * W, C, relu=1)
+    torch.cuda.synchronize()
+    assert rel_err(z.cpu(), conv.permute(0, 2, 3, 1)) < 5e-3
+    assert rel_err(y.cpu(), ref) < 1.5e-2
+    assert torch.allclose(rm.cpu(), bn.running_mean, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(rv.cpu(), bn.running_var, rtol=1e-3, atol=1e-5)
+    assert int(nbt.item()) == 1
+    # eval-mode fold
+    sc2, sh2 = zeros(C), zeros(C)
+    ops.bn_fold_eval(dev(gamma), dev(beta), rm, rv, sc2, sh2, C)
+    torch.cuda.synchronize()
+    assert torch.allclose(sc2.cpu(), gamma / torch.sqrt(bn.running_var + 1e-5), rtol=1e-3)
+    # weight gradient of the first layer
+    dz = R.bf16_round(torch.randn(N, H, W, C, generator=g))
+    refw = torch.nn.grad.conv2d_weight(x, (C, 1, 3, 3), dz.permute(0, 3, 1, 2), padding=1)
+    dw = zeros(C, 9)
+    ops.conv1_wgrad(dev(x), dev(bf(dz)), dw, N, H, W, C)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu().reshape(C, 1, 3, 3), refw) < 1e-3
+
+
+@pytest.mark.parametrize("C", [48, 96, 8, 200])
+def test_maxpool_and_bn_backward_with_pool_routing(ops, C):
+    N, H, W = 2, 12, 20
+    g = torch.Generator().manual_seed(C)
+    z = R.bf16_round(torch.randn(N, H, W, C, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    gy = R.bf16_round(torch.randn(N, H, W, C, generator=g))
+    gp = R.bf16_round(torch.randn(N, H // 2, W // 2, C, generator=g))
+    # CPU reference through autograd; y is rounded to bf16 before pooling like the stored activation
+    zc = z.clone().requires_grad_(True)
+    gam, bet = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    flat = zc.reshape(-1, C)
+    mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    ypre = (zc - mean) * invstd * gam + bet
+    y = torch.relu(ypre)
+    yq = y + (R.bf16_round(y.detach()) - y.detach())  # straight-through bf16 rounding
+    p = F.max_pool2d(yq.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    ((y * gy).sum() + (p * gp).sum()).backward()
+    # device
+    zd = dev(bf(z))
+    scale, shift = dev((gamma * invstd).detach()), dev((beta - mean * gamma * invstd).detach())
+    yd = zeros(N, H, W, C, dtype=torch.bfloat16)
+    ops.bn_act(zd, C, yd, C, scale, shift, N * H * W, C, relu=1)
+    pd = zeros(N, H // 2, W // 2, C, dtype=torch.bfloat16)
+    ops.maxpool2(yd, C, pd, C, N, H, W, C)
+    torch.cuda.synchronize()
+    assert rel_err(pd.cpu(), p.detach()) < 1e-2
+    red = zeros(ops.STAT_REPLICAS, 2, C)
+    dz = zeros(N, H, W, C, dtype=torch.bfloat16)
+    ops.bn_bwd_reduce(zd, C, dev(bf(gy)), C, dev(bf(gp)), C, dz, C, scale, shift, dev(mean.detach()), dev(invstd.detach()),
+                      red, N, H, W, C, relu=1)
+    dgam, dbet = zeros(C), zeros(C)
+    ops.bn_bwd_apply(zd, C, dz, C, dev(gamma), dev(mean.detach()), dev(invstd.detach()), red, dgam, dbet, N * H * W, C)
+    torch.cuda.synchronize()
+    assert rel_err(dz.cpu(), zc.grad) < 2e-2
+    assert rel_err(dgam.cpu(), gam.grad) < 1e-2
+    assert rel_err(dbet.cpu(), bet.grad) < 1e-2
+    # no-pool variant (plain BN + ReLU backward)
+    zc2 = z.clone().requires_grad_(True)
+    flat2 = zc2.reshape(-1, C)
+    m2, v2 = flat2.mean(0), flat2.var(0, unbiased=False)
+    y2 = torch.relu((zc2 - m2) / torch.sqrt(v2 + 1e-5) * gamma + beta)
+    (y2 * gy).sum().backward()
+    red.zero_()
+    ops.bn_bwd_reduce(zd, C, dev(bf(gy)), C, None, 0, dz, C, scale, shift, dev(mean.detach()), dev(invstd.detach()),
+                      red, N, H, W, C, relu=1)
+    ops.bn_bwd_apply(zd, C, dz, C, dev(gamma), dev(mean.detach()), dev(invstd.detach()), red, None, None, N * H * W, C)
+    torch.cuda.synchronize()
+    assert rel_err(dz.cpu(), zc2.grad) < 2e-2
+
+
+def test_dropout_mask_is_consistent_between_forward_and_backward(ops):
+    M, C, p = 4096, 64, 0.1
+    z = torch.ones(M, C, dtype=torch.bfloat16, device="cuda")
+    one, zero = torch.ones(C, device="cuda"), zeros(C)
+    y = zeros(M, C, dtype=torch.bfloat16)
+    ops.bn_act(z, C, y, C, one, zero, M, C, relu=1, drop_p=p, drop_seed=1234)
+    torch.cuda.synchronize()
+    yc = y.float().cpu()
+    kept = yc > 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.01
+    assert torch.allclose(yc[kept], torch.full_like(yc[kept], 1 / (1 - p)), rtol=1e-2)
+    dz, red = zeros(M, C, dtype=torch.bfloat16), zeros(ops.STAT_REPLICAS, 2, C)
+    ops.bn_bwd_reduce(z, C, torch.ones_like(z), C, None, 0, dz, C, one, zero, zero, one, red, 1, 1, M, C, relu=1,
+                      drop_p=p, drop_seed=1234)
+    torch.cuda.synchronize()
+    assert torch.equal(dz.float().cpu() > 0, kept)
+
+
+def test_gap_spatial_sum_colsum_broadcast(ops):
+    N, HW, C = 3, 100, 72
+    g = torch.Generator().manual_seed(3)
+    x = R.bf16_round(torch.randn(N, HW, C, generator=g))
+    xd = dev(bf(x))
+    pooled, ws = zeros(N, C, dtype=torch.bfloat16), zeros(N, C)
+    ops.gap_fwd(xd, C, pooled, ws, N, HW, C)
+    ssum = zeros(N, C, dtype=torch.bfloat16)
+    ops.spatial_sum(xd, C, ssum, ws, N, HW, C)
+    cs = zeros(C)
+    ops.colsum(xd, C, cs, N * HW, C)
+    torch.cuda.synchronize()
+    assert rel_err(pooled.cpu(), x.mean(1)) < 6e-3
+    assert rel_err(ssum.cpu(), x.sum(1)) < 6e-3
+    assert rel_err(cs.cpu(), x.reshape(-1, C).sum(0)) < 1e-4
+    # broadcast of a per-image row through bn_act, and the GAP backward accumulate
+    out = zeros(N, HW, C, dtype=torch.bfloat16)
+    ops.bn_act(pooled, C, out, C, torch.ones(C, device="cuda"), zeros(C), N * HW, C, relu=0, bcast_hw=HW)
+    dx = dev(bf(x)).clone()
+    ops.gap_bwd(pooled, dx, C, N, HW, C)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), pooled.cpu()[:, None, :].expand(N, HW, C))
+    assert rel_err(dx.cpu(), x + pooled.float().cpu()[:, None, :] / HW) < 6e-3
+
+
+@pytest.mark.parametrize("Fi,C", [(48, 96), (24, 48), (96, 192)])
+def test_attention_gate_elementwise_forward_backward(ops, Fi, C):
+    M = 2 * 16 * 16
+    g = torch.Generator().manual_seed(Fi)
+    zg, zx = R.bf16_round(torch.randn(M, Fi, generator=g)), R.bf16_round(torch.randn(M, Fi, generator=g) * 1.5 + 0.3)
+    x = R.bf16_round(torch.randn(M, C, generator=g))
+    dout = R.bf16_round(torch.randn(M, C, generator=g))
+    P = {k: (torch.rand(n, generator=g) + 0.5) for k, n in (("gg", Fi), ("gx", Fi), ("g1", 1))}
+    P.update({k: torch.randn(n, generator=g) * 0.2 for k, n in (("bg", Fi), ("bx", Fi), ("b1", 1))})
+    P["w"] = torch.randn(Fi, generator=g) / Fi ** 0.5
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    zgc, zxc, xc = zg.clone().requires_grad_(True), zx.clone().requires_grad_(True), x.clone().requires_grad_(True)
+
+    def bn(t, gam, bet):
+        m, v = t.mean(0), t.var(0, unbiased=False)
+        return (t - m) / torch.sqrt(v + 1e-5) * gam + bet, m, 1 / torch.sqrt(v + 1e-5)
+
+    ng, mg, ig = bn(zgc, leaves["gg"], leaves["bg"])
+    nx, mx, ix = bn(zxc, leaves["gx"], leaves["bx"])
+    s = torch.relu(ng + nx)
+    psi = (s * leaves["w"]).sum(1, keepdim=True)
+    n1, m1, i1 = bn(psi, leaves["g1"], leaves["b1"])
+    alpha = torch.sigmoid(n1)
+    out = xc * alpha
+    (out * dout).sum().backward()
+
+    d = lambda t: dev(t.detach().contiguous())
+    sg, hg = d(P["gg"] * ig), d(P["bg"] - mg * P["gg"] * ig)
+    sx, hx = d(P["gx"] * ix), d(P["bx"] - mx * P["gx"] * ix)
+    zgd, zxd, xd = dev(bf(zg)), dev(bf(zx)), dev(bf(x))
+    psi_pre, st1 = zeros(M), zeros(ops.STAT_REPLICAS, 2, 1)
+    ops.gate_psi(zgd, zxd, sg, hg, sx, hx, d(P["w"]), psi_pre, st1, M, Fi)
+    sc1, sh1, sm1, si1 = zeros(1), zeros(1), zeros(1), zeros(1)
+    ops.bn_finalize(st1, d(P["g1"]), d(P["b1"]), None, None, None, sc1, sh1, sm1, si1, 1, M)
+    al = zeros(M)
+    wide = zeros(M, 2 * C, dtype=torch.bfloat16)
+    ops.gate_apply(xd, C, psi_pre, sc1, sh1, al, wide, 2 * C, M, C)
+    torch.cuda.synchronize()
+    assert rel_err(psi_pre.cpu(), psi.detach()[:, 0]) < 1e-3
+    assert abs(float(sm1.item()) - float(m1.item())) < 1e-3 and abs(float(si1.item()) / float(i1.item()) - 1) < 1e-3
+    assert rel_err(wide.cpu()[:, :C], out.detach()) < 1e-2
+    assert float(wide.cpu()[:, C:].abs().max()) == 0
+    # backward
+    dx, dq, red1 = zeros(M, C, dtype=torch.bfloat16), zeros(M), zeros(ops.STAT_REPLICAS, 2, 1)
+    ops.gate_bwd1(dev(bf(dout)), C, xd, C, al, psi_pre, sm1, si1, dx, C, dq, red1, M, C)
+    ds = zeros(M, Fi, dtype=torch.bfloat16)
+    dw, redg, redx = zeros(Fi), zeros(ops.STAT_REPLICAS, 2, Fi), zeros(ops.STAT_REPLICAS, 2, Fi)
+    dg1, db1 = zeros(1), zeros(1)
+    ops.gate_bwd2(dq, psi_pre, red1, d(P["g1"]), sm1, si1, zgd, zxd, sg, hg, sx, hx, d(mg), d(ig), d(mx), d(ix),
+                  d(P["w"]), ds, dw, redg, redx, dg1, db1, M, Fi)
+    dzg, dzx = zeros(M, Fi, dtype=torch.bfloat16), zeros(M, Fi, dtype=torch.bfloat16)
+    dgg, dbg, dgx, dbx = zeros(Fi), zeros(Fi), zeros(Fi), zeros(Fi)
+    ops.gate_bwd3(ds, zgd, zxd, d(P["gg"]), d(mg), d(ig), redg, d(P["gx"]), d(mx), d(ix), redx, dzg, dzx,
+                  dgg, dbg, dgx, dbx, M, Fi)
+    torch.cuda.synchronize()
+    # the x gradient has two parts; this kernel chain produces the direct one (dout*alpha)
+    assert rel_err(dx.cpu(), (dout * alpha.detach())) < 1e-2
+    assert rel_err(dzg.cpu(), zgc.grad) < 3e-2
+    assert rel_err(dzx.cpu(), zxc.grad) < 3e-2
+    assert rel_err(dw.cpu(), leaves["w"].grad) < 1e-2
+    for got, key in ((dgg, "gg"), (dbg, "bg"), (dgx, "gx"), (dbx, "bx"), (dg1, "g1"), (db1, "b1")):
+        assert rel_err(got.cpu(), leaves[key].grad) < 2e-2, key
+
+
+def test_outconv_forward_backward(ops):
+    M, C = 3000, 48
+    g = torch.Generator().manual_seed(9)
+    y = R.bf16_round(torch.randn(M, C, generator=g))
+    w, b = torch.randn(C, generator=g) / 7, torch.randn(1, generator=g)
+    dl = torch.randn(M, generator=g)
+    logits = zeros(M)
+    ops.outconv_fwd(dev(bf(y)), C, dev(w), dev(b), logits, M, C)
+    dy, dw, db = zeros(M, C, dtype=torch.bfloat16), zeros(C), zeros(1)
+    ops.outconv_bwd(dev(bf(y)), C, dev(dl), dev(w), dy, C, dw, db, M, C)
+    torch.cuda.synchronize()
+    assert rel_err(logits.cpu(), y @ w + b) < 1e-5
+    assert rel_err(dy.cpu(), dl[:, None] * w[None, :]) < 6e-3
+    assert rel_err(dw.cpu(), (dl[:, None] * y).sum(0)) < 1e-4
+    assert abs(float(db.item()) - float(dl.sum())) < 1e-2
+
+
+def test_criterion_and_metrics_against_reference_golden(ops, golden):
+    g = golden("g2_loss.npz")
+    for tag in ("mixed", "allneg", "allpos"):
+        l, t = dev(torch.from_numpy(g[f"{tag}/logits"])), dev(torch.from_numpy(g[f"{tag}/targets"]))
+        B, _, H, W = l.shape
+        for stage in ("main", "finetune"):
+            sums, out, dl = zeros(B, 8), zeros(4), zeros(B, 1, H, W)
+            ops.criterion(l, t, sums, out, dl, B, H, W, finetune=(stage == "finetune"))
+            torch.cuda.synchronize()
+            ref_loss = float(g[f"{tag}/{stage}/loss"])
+            assert abs(float(out[0].item()) - ref_loss) < 2e-5 * max(1, abs(ref_loss)), (tag, stage)
+            ref_d = torch.from_numpy(g[f"{tag}/{stage}/dlogits"])
+            assert float((dl.cpu() - ref_d).abs().max()) < 2e-4 * float(ref_d.abs().max()) + 1e-9, (tag, stage)
+        sums, m = zeros(B, 8), zeros(2)
+        ops.seg_metrics(l, t, sums, m, B, H, W, 0.5)
+        torch.cuda.synchronize()
+        assert abs(float(m[0].item()) - float(g[f"{tag}/dice_eval"])) < 1e-5
+        assert abs(float(m[1].item()) - float(g[f"{tag}/iou"])) < 1e-5
+
+
+def test_clip_and_adamw_match_torch(ops):
+    n = 100003
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(n, generator=g)
+    pc = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pc], lr=3e-4, weight_decay=5e-4)
+    pd, md, vd = dev(p0.clone()), zeros(n), zeros(n)
+    step, ws = torch.zeros(1, dtype=torch.int64, device="cuda"), zeros(1)
+    for it in range(3):
+        grad = torch.randn(n, generator=g) * (0.01 if it == 1 else 1.0)  # step 1 is below the clip threshold
+        pc.grad = grad.clone()
+        gn = torch.nn.utils.clip_grad_norm_([pc], 1.0)
+        opt.step()
+        gd = dev(grad)
+        ops.grad_sqnorm(gd, n, 1.0, ws)
+        ops.adamw_step(pd, md, vd, gd, n, ws, step, 3e-4)
+        torch.cuda.synchronize()
+        assert abs(float(ws.item()) ** 0.5 - float(gn)) < 1e-3 * float(gn)
+        assert float((pd.cpu() - pc.detach()).abs().max()) < 2e-6
+    assert int(step.item()) == 3
+    # non-finite gradients skip the step
+    gd = dev(torch.full((n,), float("inf")))
+    before = pd.clone()
+    ops.grad_sqnorm(gd, n, 1.0, ws)
+    ops.adamw_step(pd, md, vd, gd, n, ws, step, 3e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(pd, before) and int(step.item()) == 3
+
+
+def test_pack_weights_table(ops):
+    from att_aspp_unet_amd._abi import PackEntry
+    O_, I_, k = 40, 24, 3
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(O_, I_, k, k, generator=g)
+    w_cl = w.permute(0, 2, 3, 1).contiguous()          # physical [O][kh][kw][I]
+    wt = torch.randn(16, 8, 2, 2, generator=g)         # convT IOHW
+    wt_cl = wt.permute(0, 2, 3, 1).contiguous()        # physical [I][kh][kw][O]
+    flat = torch.cat([w_cl.reshape(-1), wt_cl.reshape(-1)])
+    T = k * k
+    entries, dst, blk = [], 0, 0
+
+    def add(**kw):
+        nonlocal dst, blk
+        e = PackEntry(**kw, dst_off=dst, blk_begin=blk)
+        entries.append(e)
+        tot = e.R * e.T * e.Cpad
+        dst += tot
+        blk += (tot + 255) // 256
+        return dst - tot, tot
+
+    o1, n1 = add(src_off=0, R=O_, T=T, C=I_, Cpad=32, s_r=T * I_, s_t=I_, s_c=1, t_flip=0, R2=0, s_r2=0)
+    o2, n2 = add(src_off=0, R=I_, T=T, C=O_, Cpad=64, s_r=1, s_t=I_, s_c=T * I_, t_flip=1, R2=0, s_r2=0)
+    base = w_cl.numel()
+    o3, n3 = add(src_off=base, R=4 * 8, T=1, C=16, Cpad=32, s_r=8, s_t=0, s_c=4 * 8, t_flip=0, R2=8, s_r2=1)
+    o4, n4 = add(src_off=base, R=16, T=4, C=8, Cpad=32, s_r=4 * 8, s_t=8, s_c=1, t_flip=0, R2=0, s_r2=0)
+    arr = (PackEntry * len(entries))(*entries)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    packed = zeros(dst, dtype=torch.bfloat16)
+    ops.pack_weights(dev(flat), packed, table, len(entries), blk)
+    torch.cuda.synchronize()
+    pk = packed.float().cpu()
+    exp1 = torch.zeros(O_, T, 32); exp1[:, :, :I_] = w.permute(0, 2, 3, 1).reshape(O_, T, I_)
+    exp2 = torch.zeros(I_, T, 64); exp2[:, :, :O_] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(I_, T, O_)
+    exp3 = torch.zeros(32, 1, 32); exp3[:, 0, :16] = wt.permute(2, 3, 1, 0).reshape(32, 16)
+    exp4 = torch.zeros(16, 4, 32); exp4[:, :, :8] = wt.permute(0, 2, 3, 1).reshape(16, 4, 8)
+    for off, n, exp in ((o1, n1, exp1), (o2, n2, exp2), (o3, n3, exp3), (o4, n4, exp4)):
+        assert torch.equal(pk[off:off + n], R.bf16_round(exp).reshape(-1))
