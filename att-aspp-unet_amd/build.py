@@ -17,7 +17,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libaau.so")
 SOURCES = ["runtime.hip", "igemm.hip", "wgrad.hip", "bn.hip", "pointwise.hip", "gate.hip", "loss.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def _newer(src: str, dst: str) -> bool:

@@ -269,14 +269,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s1[ni][r] += v[r]; s2[ni][r] += v[r] * v[r]; }
             }
+            // per-channel vectors are indexed by the real output channel (co for the pixel-shuffle store)
+            const int qv = d.shuffle2x2 ? q % (d.Cout >> 2) : q;
             if (a.bias) {
-                const f32x4 b = *(const f32x4*)(a.bias + q);
+                const f32x4 b = *(const f32x4*)(a.bias + qv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += b[r];
             }
             if (a.scale) {
-                const f32x4 sc = *(const f32x4*)(a.scale + q);
-                const f32x4 sh = *(const f32x4*)(a.shift + q);
+                const f32x4 sc = *(const f32x4*)(a.scale + qv);
+                const f32x4 sh = *(const f32x4*)(a.shift + qv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
             }

@@ -1,0 +1,589 @@
+"""Static execution plans for the Attention-ASPP-UNet hot path on one MI355X.
+
+The network graph is fixed (attention_aspp_unet_pipeline_stage.py:123-127), so for every
+(batch, height, width, train/eval) the engine records ONCE the full list of kernel
+launches of the forward pass and of the hand-written backward pass, with every buffer
+pre-allocated and every pointer resolved.  A step is then a replay of those lists:
+no allocator traffic, no autograd graph over the internals, no host synchronisation,
+and therefore capturable as one hipGraph.
+
+Memory layout (all resident in HBM for the life of the plan):
+  * parameters / gradients / Adam moments: three flat fp32 buffers; each nn.Parameter is a
+    view into them (4-D weights in channels_last = [O][KH][KW][I] physical order, which is
+    the K-contiguous GEMM operand order), so clip + AdamW are launches over one buffer;
+  * packed bf16 GEMM operands of all conv weights (forward and data-gradient forms),
+    refreshed by one table-driven launch per step;
+  * activations: NHWC bf16; decoder concat buffers are written in place by their
+    producers (skip half by the encoder / attention gate, upsampled half by the
+    ConvTranspose GEMM), never copied.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable
+
+import torch
+import torch.nn as nn
+
+from . import _abi, ops
+from ._abi import ConvDesc, PackEntry, STAT_REPLICAS
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+ALIGN = 64  # elements; keeps every parameter 256-byte aligned inside the flat buffers
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Rec:
+    """Recorded launch list.  Tensors are turned into raw pointers at record time and kept alive."""
+
+    def __init__(self):
+        self.ops = []
+        self.keep = []
+
+    def add(self, name, *args):
+        f = _abi.fn(name)
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                self.keep.append(a)
+                conv.append(a.data_ptr())
+            elif isinstance(a, ConvDesc):
+                self.keep.append(a)
+                conv.append(C.byref(a))
+            else:
+                conv.append(a)
+        self.ops.append((f, tuple(conv), name))
+
+    def callback(self, fn: Callable[[], None]):
+        self.ops.append((None, fn, "callback"))
+
+    def run(self, stream: int):
+        for f, a, name in self.ops:
+            if f is None:
+                a()
+                continue
+            rc = f(*a, stream)
+            if rc != 0:
+                _abi.check(rc, name)
+
+
+class _Arena:
+    def __init__(self, n, device, dtype=F32):
+        self.buf = torch.zeros(max(int(n), 16), dtype=dtype, device=device)
+        self.off = 0
+
+    def take(self, n):
+        n4 = _ru(int(n), 4)
+        if self.off + n4 > self.buf.numel():
+            raise RuntimeError("arena exhausted")
+        t = self.buf[self.off:self.off + n]
+        self.off += n4
+        return t
+
+
+class ConvP:
+    """One convolution's weights inside the flat store."""
+    __slots__ = ("name", "kind", "param", "O", "I", "k", "dil", "w", "dw", "pk_f", "pk_d", "cpad_f", "cpad_d",
+                 "bias", "dbias")
+
+
+class BNP:
+    __slots__ = ("name", "C", "gamma", "beta", "rm", "rv", "nbt", "dgamma", "dbeta")
+
+
+class ParamStore:
+    """Flat fp32 parameter / gradient buffers, packed bf16 operands and the pack table."""
+
+    def __init__(self, model: nn.Module, device):
+        self.device = device
+        named = list(model.named_parameters())
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += _ru(p.numel(), ALIGN)
+        self.total = total
+        self.flat = torch.zeros(total, dtype=F32, device=device)
+        self.gflat = torch.zeros(total, dtype=F32, device=device)
+        self.offs = dict(zip(self.names, offs))
+        self.pviews, self.gviews = {}, {}
+        for (name, p), off in zip(named, offs):
+            pv, gv = self._view(self.flat, off, p.shape), self._view(self.gflat, off, p.shape)
+            with torch.no_grad():
+                pv.copy_(p.data.to(device=device, dtype=F32))
+            p.data = pv
+            p.grad = None
+            self.pviews[name], self.gviews[name] = pv, gv
+        self._ptrs = [p.data_ptr() for p in self.params]
+        self.m = self.v = None  # Adam moments, allocated by the optimiser
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        self.norm_ws = torch.zeros(4, dtype=F32, device=device)
+        self._build_pack(model)
+
+    @staticmethod
+    def _view(flat, off, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        t = flat[off:off + n]
+        if len(shape) == 4:
+            d0, d1, d2, d3 = shape
+            return t.view(d0, d2, d3, d1).permute(0, 3, 1, 2)  # logical OIHW, physical [O][KH][KW][I]
+        return t.view(*shape)
+
+    def intact(self) -> bool:
+        return all(p.data_ptr() == q for p, q in zip(self.params, self._ptrs))
+
+    def bind_grads(self):
+        for name, p in zip(self.names, self.params):
+            g = self.gviews[name]
+            if p.grad is not g:
+                p.grad = g
+
+    # ---- packed operands ----
+    def _build_pack(self, model):
+        self.convs: dict[str, ConvP] = {}
+        self.bns: dict[str, BNP] = {}
+        entries, dst, blk = [], 0, 0
+
+        def add_entry(**kw):
+            nonlocal dst, blk
+            e = PackEntry(dst_off=dst, blk_begin=blk, **kw)
+            entries.append(e)
+            n = e.R * e.T * e.Cpad
+            off = dst
+            dst += _ru(n, 8)
+            blk += (n + 255) // 256
+            return off, n
+
+        mods = dict(model.named_modules())
+        for mname, m in mods.items():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                cp = ConvP()
+                cp.name, cp.param = mname, m.weight
+                wname = mname + ".weight"
+                cp.w, cp.dw = self.pviews[wname], self.gviews[wname]
+                cp.bias = self.pviews.get(mname + ".bias")
+                cp.dbias = self.gviews.get(mname + ".bias")
+                src = self.offs[wname]
+                cp.pk_f = cp.pk_d = None
+                cp.cpad_f = cp.cpad_d = 0
+                if isinstance(m, nn.ConvTranspose2d):
+                    cp.kind, cp.I, cp.O, cp.k, cp.dil = "convT", m.in_channels, m.out_channels, 2, 1
+                    I_, O_ = cp.I, cp.O
+                    cp.cpad_f, cp.cpad_d = ops.cpad_of(I_), ops.cpad_of(O_)
+                    cp.pk_f = add_entry(src_off=src, R=4 * O_, T=1, C=I_, Cpad=cp.cpad_f, s_r=O_, s_t=0, s_c=4 * O_,
+                                        t_flip=0, R2=O_, s_r2=1)
+                    cp.pk_d = add_entry(src_off=src, R=I_, T=4, C=O_, Cpad=cp.cpad_d, s_r=4 * O_, s_t=O_, s_c=1,
+                                        t_flip=0, R2=0, s_r2=0)
+                else:
+                    cp.O, cp.I, cp.k, cp.dil = m.out_channels, m.in_channels, m.kernel_size[0], m.dilation[0]
+                    T = cp.k * cp.k
+                    if cp.I % 8 != 0:
+                        cp.kind = "first"      # Conv2d(1, C, 3): direct kernel, fp32 weights
+                    elif cp.O % 8 != 0:
+                        cp.kind = "rowdot"     # Conv2d(C, 1, 1): out_conv / psi, fp32 weights
+                    else:
+                        cp.kind = "conv"
+                        cp.cpad_f, cp.cpad_d = ops.cpad_of(cp.I), ops.cpad_of(cp.O)
+                        cp.pk_f = add_entry(src_off=src, R=cp.O, T=T, C=cp.I, Cpad=cp.cpad_f, s_r=T * cp.I,
+                                            s_t=cp.I, s_c=1, t_flip=0, R2=0, s_r2=0)
+                        cp.pk_d = add_entry(src_off=src, R=cp.I, T=T, C=cp.O, Cpad=cp.cpad_d, s_r=1, s_t=cp.I,
+                                            s_c=T * cp.I, t_flip=1, R2=0, s_r2=0)
+                self.convs[mname] = cp
+            elif isinstance(m, nn.BatchNorm2d):
+                b = BNP()
+                b.name, b.C = mname, m.num_features
+                b.gamma, b.beta = self.pviews[mname + ".weight"], self.pviews[mname + ".bias"]
+                b.dgamma, b.dbeta = self.gviews[mname + ".weight"], self.gviews[mname + ".bias"]
+                b.rm, b.rv, b.nbt = m.running_mean, m.running_var, m.num_batches_tracked
+                self.bns[mname] = b
+        self.packed = torch.zeros(max(dst, 8), dtype=BF16, device=self.device)
+        for cp in self.convs.values():
+            for key in ("pk_f", "pk_d"):
+                v = getattr(cp, key)
+                if v is not None:
+                    setattr(cp, key, self.packed[v[0]:v[0] + v[1]])
+        arr = (PackEntry * len(entries))(*entries)
+        self.pack_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self.pack_n, self.pack_blocks = len(entries), blk
+        self.bn_channels = sum(b.C for b in self.bns.values())
+
+    def buffers_intact(self, model) -> bool:
+        mods = dict(model.named_modules())
+        for name, b in self.bns.items():
+            m = mods[name]
+            if b.rm is not m.running_mean or b.rv is not m.running_var or b.nbt is not m.num_batches_tracked:
+                return False
+        return True
+
+
+class Plan:
+    """Recorded forward (and backward) launch lists for one input shape / mode."""
+
+    def __init__(self, eng: "Engine", B: int, H: int, W: int, train: bool):
+        assert H % 16 == 0 and W % 16 == 0, "H and W must be multiples of 16 (four 2x2 poolings)"
+        if train:
+            assert B >= 2, "training-mode BatchNorm of the ASPP image-pool branch needs batch >= 2 (pipeline:75-77)"
+        self.eng, self.B, self.H, self.W, self.train = eng, B, H, W, train
+        self.dev = eng.store.device
+        self.fwd, self.bwd = _Rec(), _Rec()
+        self.drop_seed = C.c_uint64(0)
+        self.drop_p = float(eng.model.bridge.project[3].p) if train else 0.0
+        st = eng.store
+        nbn = st.bn_channels + 8
+        self.stats_arena = _Arena(STAT_REPLICAS * 2 * nbn, self.dev)
+        self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3, self.dev)
+        self.vec_arena = _Arena(nbn * 8 + 64, self.dev)
+        self.x = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
+        self.logits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
+        self.dlogits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev) if train else None
+        self.bwd_blocks = []   # per forward block: list of (name, args) recorded later in reverse
+        self.bucket_hooks = {}  # block index -> callback fired after that block's backward
+        self._build()
+
+    # ---- small helpers ----
+    def new(self, *shape, dtype=BF16):
+        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+
+    def bnbuf(self, C_):
+        va = self.vec_arena
+        return dict(stats=self.stats_arena.take(STAT_REPLICAS * 2 * C_), scale=va.take(C_), shift=va.take(C_),
+                    mean=va.take(C_), invstd=va.take(C_), red=self.red_arena.take(STAT_REPLICAS * 2 * C_))
+
+    def _bn_finalize(self, bn: BNP, w, count):
+        self.fwd.add("aau_bn_finalize", w["stats"], bn.gamma, bn.beta, bn.rm, bn.rv, bn.nbt, w["scale"], w["shift"],
+                     w["mean"], w["invstd"], bn.C, count, 1e-5, 0.1)
+
+    def _bn_fold(self, bn: BNP, w):
+        self.fwd.add("aau_bn_fold_eval", bn.gamma, bn.beta, bn.rm, bn.rv, w["scale"], w["shift"], bn.C, 1e-5)
+
+    # ---- ConvBNReLU on MFMA: forward ----
+    def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0):
+        """conv(cname) -> BN(bname) -> ReLU; returns the per-layer record used by the backward."""
+        st = self.eng.store
+        cv, bn = st.convs[cname], st.bns[bname]
+        M = N * H * W
+        pad = cv.dil * (cv.k // 2)
+        w = self.bnbuf(bn.C)
+        rec = dict(cv=cv, bn=bn, w=w, N=N, H=H, W=W, M=M, src=src, sp=sp, drop=drop, bcast_hw=bcast_hw)
+        if self.train:
+            z = self.new(M, cv.O)
+            d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f)
+            self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
+            self._bn_finalize(bn, w, M)
+            Mo = M * bcast_hw if bcast_hw else M
+            self.fwd.add("aau_bn_act", z, cv.O, ydst, yp, w["scale"], w["shift"], Mo, cv.O, 1, bcast_hw,
+                         self.drop_p if drop else 0.0, self.drop_seed)
+            rec["z"] = z
+        else:
+            self._bn_fold(bn, w)
+            if bcast_hw:
+                z = self.new(M, cv.O)
+                d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f)
+                self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, None)
+                self.fwd.add("aau_bn_act", z, cv.O, ydst, yp, w["scale"], w["shift"], M * bcast_hw, cv.O, 1,
+                             bcast_hw, 0.0, self.drop_seed)
+            else:
+                d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, yp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f, relu=1)
+                self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, ydst, None, w["scale"], w["shift"], None)
+        return rec
+
+    # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
+    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0):
+        cv, bn, w = r["cv"], r["bn"], r["w"]
+        N, H, W, M = r["N"], r["H"], r["W"], r["M"]
+        b = self.bwd
+        dz = self.new(M, cv.O)
+        b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, dpool, dpp, dz, cv.O, w["scale"], w["shift"], w["mean"],
+              w["invstd"], w["red"], N, H, W, cv.O, 1, self.drop_p if r["drop"] else 0.0, self.drop_seed)
+        b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
+              bn.dbeta, M, cv.O)
+        pad = cv.dil * (cv.k // 2)
+        if cv.kind == "first":
+            b.add("aau_conv1_wgrad", r["src"], dz, cv.dw, N, H, W, cv.O)
+            return dz
+        dwd = ops.conv_desc(N, H, W, cv.I, r["sp"], H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil)
+        b.add("aau_conv_wgrad", dwd, r["src"], dz, cv.dw)
+        if din is not None:
+            dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
+                               accumulate=accumulate)
+            b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, None)
+        return dz
+
+    # ---- graph ----
+    def _build(self):
+        eng, st, f, B, H, W = self.eng, self.eng.store, self.fwd, self.B, self.H, self.W
+        model = eng.model
+        c = st.convs["d1.0.block.0"].O
+        tr = self.train
+        Hs = [H, H // 2, H // 4, H // 8, H // 16]
+        Ws = [W, W // 2, W // 4, W // 8, W // 16]
+        Ms = [B * h * w for h, w in zip(Hs, Ws)]
+        Cs = [c, 2 * c, 4 * c, 8 * c, 16 * c]
+
+        # weights: one table-driven repack per step
+        f.add("aau_pack_weights", st.flat, st.packed, st.pack_table, st.pack_n, st.pack_blocks)
+
+        # ---------------- encoder ----------------
+        cat1 = self.new(Ms[0], 2 * c)               # [x1 | up(d2)] for u1 (no gate): x1 is produced in place
+        skips = [cat1, self.new(Ms[1], Cs[1]), self.new(Ms[2], Cs[2]), self.new(Ms[3], Cs[3])]
+        skip_p = [2 * c, Cs[1], Cs[2], Cs[3]]
+        pools = [self.new(Ms[i + 1], Cs[i]) for i in range(4)]
+        enc = []  # (rec0, rec1) per level
+        # d1.0: direct kernel on the fp32 frame
+        cv0, bn0 = st.convs["d1.0.block.0"], st.bns["d1.0.block.1"]
+        w0 = self.bnbuf(c)
+        y10 = self.new(Ms[0], c)
+        r10 = dict(cv=cv0, bn=bn0, w=w0, N=B, H=H, W=W, M=Ms[0], src=self.x, sp=1, drop=False, bcast_hw=0)
+        z10 = self.new(Ms[0], c)
+        r10["z"] = z10
+        if tr:
+            f.add("aau_conv1_fwd", self.x, cv0.w, z10, w0["stats"], B, H, W, c)
+            self._bn_finalize(bn0, w0, Ms[0])
+        else:
+            f.add("aau_conv1_fwd", self.x, cv0.w, z10, None, B, H, W, c)
+            self._bn_fold(bn0, w0)
+        f.add("aau_bn_act", z10, c, y10, c, w0["scale"], w0["shift"], Ms[0], c, 1, 0, 0.0, self.drop_seed)
+        r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, cat1, 2 * c)
+        enc.append((r10, r11))
+        f.add("aau_maxpool2", cat1, 2 * c, pools[0], c, B, H, W, c)
+        for lv in range(1, 4):
+            h, w_ = Hs[lv], Ws[lv]
+            ya = self.new(Ms[lv], Cs[lv])
+            ra = self.cbr_fwd(f"d{lv + 1}.0.block.0", f"d{lv + 1}.0.block.1", pools[lv - 1], Cs[lv - 1], B, h, w_,
+                              ya, Cs[lv])
+            rb = self.cbr_fwd(f"d{lv + 1}.1.block.0", f"d{lv + 1}.1.block.1", ya, Cs[lv], B, h, w_, skips[lv],
+                              Cs[lv])
+            enc.append((ra, rb))
+            f.add("aau_maxpool2", skips[lv], Cs[lv], pools[lv], Cs[lv], B, h, w_, Cs[lv])
+
+        # ---------------- bridge: ASPP ----------------
+        h5, w5, M5 = Hs[4], Ws[4], Ms[4]
+        Cb = Cs[4]
+        nbr = len(model.bridge.blocks)
+        ncat = (nbr + 1) * Cb
+        cat5 = self.new(M5, ncat)
+        p4 = pools[3]
+        br = [self.cbr_fwd(f"bridge.blocks.{i}.0", f"bridge.blocks.{i}.1", p4, Cs[3], B, h5, w5,
+                           cat5[:, i * Cb:], ncat) for i in range(nbr)]
+        pooled = self.new(B, Cs[3])
+        gap_ws = self.new(B, max(Cs[3], Cb), dtype=F32)
+        f.add("aau_gap_fwd", p4, Cs[3], pooled, gap_ws, B, h5 * w5, Cs[3])
+        rpool = self.cbr_fwd("bridge.pool.1", "bridge.pool.2", pooled, Cs[3], B, 1, 1, cat5[:, nbr * Cb:], ncat,
+                             bcast_hw=h5 * w5)
+        bout = self.new(M5, Cb)
+        rproj = self.cbr_fwd("bridge.project.0", "bridge.project.1", cat5, ncat, B, h5, w5, bout, Cb, drop=True)
+
+        # ---------------- decoder ----------------
+        dec = []
+        g_in, g_c = bout, Cb
+        for lv in (3, 2, 1, 0):
+            name = f"u{lv + 1}"
+            Co = Cs[lv]
+            hi, wi = Hs[lv + 1], Ws[lv + 1]     # input grid of the up-conv
+            ho, wo, Mo = Hs[lv], Ws[lv], Ms[lv]
+            up = st.convs[f"{name}.up"]
+            cat = cat1 if lv == 0 else self.new(Mo, 2 * Co)
+            dup = ops.conv_desc(B, hi, wi, g_c, g_c, hi, wi, 4 * Co, 2 * Co, Cpad=up.cpad_f, shuffle2x2=1)
+            f.add("aau_conv_igemm", dup, g_in, up.pk_f, cat[:, Co:], up.bias, None, None, None)
+            gate = None
+            if lv > 0:
+                Fi = Co // 2
+                wg, wx = st.convs[f"{name}.att.Wg.0"], st.convs[f"{name}.att.Wx.0"]
+                bg, bx, b1 = st.bns[f"{name}.att.Wg.1"], st.bns[f"{name}.att.Wx.1"], st.bns[f"{name}.att.psi.1"]
+                psi = st.convs[f"{name}.att.psi.0"]
+                wgb, wxb, w1 = self.bnbuf(Fi), self.bnbuf(Fi), self.bnbuf(1)
+                zg, zx = self.new(Mo, Fi), self.new(Mo, Fi)
+                psi_pre = self.new(Mo, dtype=F32)
+                alpha = self.new(Mo, dtype=F32)
+                dg = ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi, Cpad=wg.cpad_f)
+                dx = ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi, Cpad=wx.cpad_f)
+                f.add("aau_conv_igemm", dg, cat[:, Co:], wg.pk_f, zg, None, None, None, wgb["stats"] if tr else None)
+                f.add("aau_conv_igemm", dx, skips[lv], wx.pk_f, zx, None, None, None, wxb["stats"] if tr else None)
+                if tr:
+                    self._bn_finalize(bg, wgb, Mo)
+                    self._bn_finalize(bx, wxb, Mo)
+                else:
+                    self._bn_fold(bg, wgb)
+                    self._bn_fold(bx, wxb)
+                f.add("aau_gate_psi", zg, zx, wgb["scale"], wgb["shift"], wxb["scale"], wxb["shift"], psi.w, psi_pre,
+                      w1["stats"] if tr else None, Mo, Fi)
+                if tr:
+                    self._bn_finalize(b1, w1, Mo)
+                else:
+                    self._bn_fold(b1, w1)
+                f.add("aau_gate_apply", skips[lv], skip_p[lv], psi_pre, w1["scale"], w1["shift"], alpha, cat, 2 * Co,
+                      Mo, Co)
+                gate = dict(wg=wg, wx=wx, psi=psi, bg=bg, bx=bx, b1=b1, wgb=wgb, wxb=wxb, w1=w1, zg=zg, zx=zx,
+                            psi_pre=psi_pre, alpha=alpha, Fi=Fi)
+            ya = self.new(Mo, Co)
+            ra = self.cbr_fwd(f"{name}.conv.0.block.0", f"{name}.conv.0.block.1", cat, 2 * Co, B, ho, wo, ya, Co)
+            yb = self.new(Mo, Co)
+            rb = self.cbr_fwd(f"{name}.conv.1.block.0", f"{name}.conv.1.block.1", ya, Co, B, ho, wo, yb, Co)
+            dec.append(dict(lv=lv, name=name, up=up, cat=cat, gate=gate, ra=ra, rb=rb, g_in=g_in, g_c=g_c, Co=Co,
+                            hi=hi, wi=wi, ho=ho, wo=wo, Mo=Mo, out=yb))
+            g_in, g_c = yb, Co
+        oc = st.convs["out_conv"]
+        f.add("aau_outconv_fwd", g_in, c, oc.w, oc.bias, self.logits, Ms[0], c)
+        if not tr:
+            return
+
+        # =============================== backward ===============================
+        b = self.bwd
+        mark = self._mark
+        dy = self.new(Ms[0], c)
+        b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, Ms[0], c)
+        dskip = [None, self.new(Ms[1], Cs[1]), self.new(Ms[2], Cs[2]), self.new(Ms[3], Cs[3])]
+        dcat1 = None
+        for blk in reversed(dec):            # u1, u2, u3, u4
+            lv, Co, Mo, ho, wo, hi, wi = blk["lv"], blk["Co"], blk["Mo"], blk["ho"], blk["wo"], blk["hi"], blk["wi"]
+            dya = self.new(Mo, Co)
+            self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co)
+            dcat = self.new(Mo, 2 * Co)
+            self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=2 * Co)
+            if lv == 0:
+                dcat1 = dcat
+            cat, gt, up = blk["cat"], blk["gate"], blk["up"]
+            if gt is not None:
+                Fi = gt["Fi"]
+                w1, wgb, wxb = gt["w1"], gt["wgb"], gt["wxb"]
+                dq = self.new(Mo, dtype=F32)
+                ds, dzg, dzx = self.new(Mo, Fi), self.new(Mo, Fi), self.new(Mo, Fi)
+                red1 = w1["red"]
+                b.add("aau_gate_bwd1", dcat, 2 * Co, skips[lv], skip_p[lv], gt["alpha"], gt["psi_pre"], w1["mean"],
+                      w1["invstd"], dskip[lv], Co, dq, red1, Mo, Co)
+                b.add("aau_gate_bwd2", dq, gt["psi_pre"], red1, gt["b1"].gamma, w1["mean"], w1["invstd"], gt["zg"],
+                      gt["zx"], wgb["scale"], wgb["shift"], wxb["scale"], wxb["shift"], wgb["mean"], wgb["invstd"],
+                      wxb["mean"], wxb["invstd"], gt["psi"].w, ds, gt["psi"].dw, wgb["red"], wxb["red"],
+                      gt["b1"].dgamma, gt["b1"].dbeta, Mo, Fi)
+                b.add("aau_gate_bwd3", ds, gt["zg"], gt["zx"], gt["bg"].gamma, wgb["mean"], wgb["invstd"], wgb["red"],
+                      gt["bx"].gamma, wxb["mean"], wxb["invstd"], wxb["red"], dzg, dzx, gt["bg"].dgamma,
+                      gt["bg"].dbeta, gt["bx"].dgamma, gt["bx"].dbeta, Mo, Fi)
+                wg, wx = gt["wg"], gt["wx"]
+                b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], dzg, wg.dw)
+                b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], dzx,
+                      wx.dw)
+                b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, 2 * Co, Cpad=wg.cpad_d,
+                                                      accumulate=1), dzg, wg.pk_d, dcat[:, Co:], None, None, None,
+                      None)
+                b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, Co, Cpad=wx.cpad_d,
+                                                      accumulate=1), dzx, wx.pk_d, dskip[lv], None, None, None, None)
+            # ConvTranspose2d backward: bias, weight, input
+            gsrc, gc = blk["g_in"], blk["g_c"]
+            b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, Mo, Co)
+            b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1),
+                  dcat[:, Co:], gsrc, up.dw)
+            dg_in = self.new(B * hi * wi, gc)
+            b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1, up.cpad_d),
+                  dcat[:, Co:], up.pk_d, dg_in, None, None, None, None)
+            dy = dg_in
+            mark(blk["name"])
+        # bridge
+        dcat5 = self.new(M5, ncat)
+        self.cbr_bwd(rproj, dy, Cb, din=dcat5, dinp=ncat)
+        dp4 = self.new(M5, Cs[3])
+        for i, r in enumerate(br):
+            self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0)
+        dpb = self.new(B, Cb)
+        b.add("aau_spatial_sum", dcat5[:, nbr * Cb:], ncat, dpb, gap_ws, B, h5 * w5, Cb)
+        dpooled = self.new(B, Cs[3])
+        rpool_b = dict(rpool)
+        rpool_b["bcast_hw"] = 0
+        self.cbr_bwd(rpool_b, dpb, Cb, din=dpooled, dinp=Cs[3])
+        b.add("aau_gap_bwd", dpooled, dp4, Cs[3], B, h5 * w5, Cs[3])
+        mark("bridge")
+        # encoder
+        dpool = dp4
+        for lv in (3, 2, 1, 0):
+            ra, rb = enc[lv]
+            if lv == 0:
+                dsk, dskp = dcat1, 2 * c
+            else:
+                dsk, dskp = dskip[lv], Cs[lv]
+            dya = self.new(Ms[lv], Cs[lv])
+            self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv])
+            if lv > 0:
+                dprev = self.new(Ms[lv], Cs[lv - 1])
+                self.cbr_bwd(ra, dya, Cs[lv], din=dprev, dinp=Cs[lv - 1])
+                dpool = dprev
+            else:
+                self.cbr_bwd(ra, dya, Cs[lv])
+            mark(f"d{lv + 1}")
+
+    def _mark(self, name):
+        cb = self.eng.bucket_callback(name)
+        if cb is not None:
+            self.bwd.callback(cb)
+
+    # ---- execution ----
+    def run_forward(self, x: torch.Tensor):
+        stream = torch.cuda.current_stream().cuda_stream
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
+        if self.train:
+            self.stats_arena.buf.zero_()
+            self.drop_seed.value = self.eng.next_seed()
+        self.fwd.run(stream)
+        return self.logits
+
+    def run_backward(self, dlogits: torch.Tensor | None):
+        stream = torch.cuda.current_stream().cuda_stream
+        st = self.eng.store
+        if dlogits is not None and dlogits.data_ptr() != self.dlogits.data_ptr():
+            self.dlogits.copy_(dlogits.reshape(self.dlogits.shape), non_blocking=True)
+        self.red_arena.buf.zero_()
+        st.gflat.zero_()
+        self.bwd.run(stream)
+        st.bind_grads()
+
+
+class Engine:
+    """Owns the flat parameter store and the plans of one model instance."""
+
+    def __init__(self, model: nn.Module):
+        self.model = model
+        self.store: ParamStore | None = None
+        self.plans: dict = {}
+        self._seed = 0x5EED
+        self.bucket_cb = None   # set by the data-parallel wrapper: name -> callable
+
+    def next_seed(self) -> int:
+        self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self._seed
+
+    def bucket_callback(self, name):
+        if self.bucket_cb is None:
+            return None
+        return lambda n=name: self.bucket_cb(n)
+
+    def ensure(self, device):
+        _abi.lib()  # fail loudly if the HIP library is missing
+        if device.type != "cuda":
+            raise _abi.AauError("the MI355X path needs CUDA/HIP tensors; there is no CPU fallback "
+                                "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+        if self.store is None or self.store.device != device or not self.store.intact() \
+                or not self.store.buffers_intact(self.model):
+            first = next(self.model.parameters())
+            if first.device != device:
+                raise _abi.AauError(f"model parameters are on {first.device}, input on {device}")
+            old = self.store
+            self.store = ParamStore(self.model, device)
+            if old is not None and old.m is not None and old.total == self.store.total:
+                self.store.m, self.store.v, self.store.step_dev = old.m, old.v, old.step_dev
+            self.plans.clear()
+        return self.store
+
+    def plan(self, B, H, W, train) -> Plan:
+        key = (B, H, W, bool(train), float(self.model.bridge.project[3].p) if train else 0.0,
+               self.bucket_cb is not None)
+        p = self.plans.get(key)
+        if p is None:
+            p = Plan(self, B, H, W, bool(train))
+            self.plans[key] = p
+        return p

@@ -1,0 +1,151 @@
+"""Drop-in ``nn.Module`` surface of the reference model, executed by the HIP engine.
+
+Class names, constructor signatures, child attribute names and therefore the 196
+``state_dict`` keys are those of attention_aspp_unet_pipeline_stage.py:59-127
+(``ConvBNReLU``, ``ASPP``, ``AttentionGate``, ``DummyAttention``, ``UpBlock``,
+``AttentionASPPUNet``).  The child ``nn.Conv2d`` / ``nn.BatchNorm2d`` /
+``nn.ConvTranspose2d`` objects are parameter containers only (created in the reference's
+order, so the same ``torch.manual_seed`` gives bit-identical initial weights and a
+reference checkpoint loads with ``strict=True``); their ATen ``forward`` is never
+called.  ``AttentionASPPUNet.forward`` replays the engine's recorded launch list; the
+backward pass is the engine's own, attached to autograd as a single node.
+
+There is no CPU / ATen fallback: calling the model on a non-HIP tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .engine import Engine
+
+
+def _conv_bn(in_c, out_c, k, dilation=1, relu=True):
+    layers = [nn.Conv2d(in_c, out_c, k, padding=dilation * (k // 2), dilation=dilation, bias=False),
+              nn.BatchNorm2d(out_c)]
+    if relu:
+        layers.append(nn.ReLU(True))
+    return nn.Sequential(*layers)
+
+
+def _no_standalone(self, *a, **k):
+    raise _abi.AauError(
+        f"{type(self).__name__} is a parameter container of the HIP engine; run it through "
+        "AttentionASPPUNet (or att_aspp_unet_amd.blocks for single-block execution)")
+
+
+class ConvBNReLU(nn.Module):
+    """pipeline:59-65."""
+
+    def __init__(self, in_c, out_c, k=3):
+        super().__init__()
+        self.block = _conv_bn(in_c, out_c, k)
+
+    forward = _no_standalone
+
+
+class ASPP(nn.Module):
+    """pipeline:67-83 (``rates`` may have any length here; the reference supports exactly three)."""
+
+    def __init__(self, in_c, out_c=256, rates=(6, 12, 18)):
+        super().__init__()
+        self.blocks = nn.ModuleList([_conv_bn(in_c, out_c, 1)] + [_conv_bn(in_c, out_c, 3, r) for r in rates])
+        self.pool = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_c, out_c, 1, bias=False),
+                                  nn.BatchNorm2d(out_c), nn.ReLU(True))
+        self.project = nn.Sequential(nn.Conv2d(out_c * (len(rates) + 2), out_c, 1, bias=False),
+                                     nn.BatchNorm2d(out_c), nn.ReLU(True), nn.Dropout(0.1))
+
+    forward = _no_standalone
+
+
+class AttentionGate(nn.Module):
+    """pipeline:85-92."""
+
+    def __init__(self, Fg, Fl, Fint):
+        super().__init__()
+        self.Wg = _conv_bn(Fg, Fint, 1, relu=False)
+        self.Wx = _conv_bn(Fl, Fint, 1, relu=False)
+        self.psi = nn.Sequential(nn.Conv2d(Fint, 1, 1, bias=False), nn.BatchNorm2d(1), nn.Sigmoid())
+        self.relu = nn.ReLU(True)
+
+    forward = _no_standalone
+
+
+class DummyAttention(nn.Module):
+    """pipeline:95-96."""
+
+    def forward(self, g, x):
+        return x
+
+
+class UpBlock(nn.Module):
+    """pipeline:98-109."""
+
+    def __init__(self, in_c, out_c, use_att=True):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(in_c, out_c, 2, 2)
+        self.att = AttentionGate(out_c, out_c, out_c // 2) if use_att else DummyAttention()
+        self.conv = nn.Sequential(ConvBNReLU(in_c, out_c), ConvBNReLU(out_c, out_c))
+
+    forward = _no_standalone
+
+
+class _NetFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward and backward are engine plans."""
+
+    @staticmethod
+    def forward(ctx, x, trigger, plan):
+        ctx.plan = plan
+        out = plan.run_forward(x)
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.plan.run_backward(dlogits.contiguous())
+        return None, None, None
+
+
+class AttentionASPPUNet(nn.Module):
+    """pipeline:111-127.  ``forward(x: [B,1,H,W] fp32) -> logits [B,1,H,W] fp32``; H, W multiples of 16."""
+
+    def __init__(self, in_channels=1, num_classes=1, base_c=32, rates=(6, 12, 18)):
+        super().__init__()
+        if in_channels != 1 or num_classes != 1:
+            raise _abi.AauError("the HIP path implements the reference configuration in_channels=1, num_classes=1")
+        if base_c % 8 != 0:
+            raise _abi.AauError("base_c must be a multiple of 8 (16-byte channel vectors)")
+        c = base_c
+        prev = in_channels
+        for i, w in enumerate((c, 2 * c, 4 * c, 8 * c), start=1):
+            setattr(self, f"d{i}", nn.Sequential(ConvBNReLU(prev, w), ConvBNReLU(w, w)))
+            setattr(self, f"p{i}", nn.MaxPool2d(2))
+            prev = w
+        self.bridge = ASPP(8 * c, 16 * c, rates=rates)
+        self.u4 = UpBlock(16 * c, 8 * c)
+        self.u3 = UpBlock(8 * c, 4 * c)
+        self.u2 = UpBlock(4 * c, 2 * c)
+        self.u1 = UpBlock(2 * c, c, use_att=False)
+        self.out_conv = nn.Conv2d(c, num_classes, 1)
+        self.base_c = base_c
+        object.__setattr__(self, "_engine", Engine(self))
+        object.__setattr__(self, "_trigger", None)
+
+    @property
+    def engine(self) -> Engine:
+        return self._engine
+
+    def _plan_for(self, x):
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise _abi.AauError(f"expected input [B,1,H,W], got {tuple(x.shape)}")
+        self._engine.ensure(x.device)
+        return self._engine.plan(x.shape[0], x.shape[2], x.shape[3], self.training)
+
+    def forward(self, x):
+        plan = self._plan_for(x)
+        x = x.float().contiguous()
+        if self.training and torch.is_grad_enabled():
+            if self._trigger is None or self._trigger.device != x.device:
+                object.__setattr__(self, "_trigger", torch.zeros(1, device=x.device, requires_grad=True))
+            return _NetFn.apply(x, self._trigger, plan)
+        return plan.run_forward(x).clone()

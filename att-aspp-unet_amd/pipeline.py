@@ -1,0 +1,171 @@
+"""Entry points of attention_aspp_unet_pipeline_stage.py restated over the HIP path:
+``train`` (:244-333), ``evaluate`` (:235-241), ``predict_prob_tta`` (:336-338),
+``load_state_dict_compat`` (:134-141), ``get_args`` (:539-550) and the module constants
+(:29-31).  Dataset reading / augmentation (cv2, albumentations) and the contour
+post-processing are outside the hot path; ``train``
+therefore consumes any iterable of ``(x [B,1,H,W] fp32, y [B,1,H,W] {0,1})`` batches and
+ships a synthetic-phantom loader for the machines that have no data.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import random
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import ops, synth
+from .losses import ComboLoss, DiceLoss, EdgeLoss, build_criterion, seg_metrics
+from .model import AttentionASPPUNet
+from .optim import FusedAdamW
+
+SEED, IMG_SIZE, WEIGHT_DECAY, GRAD_CLIP = 2025, 512, 5e-4, 1.0
+EARLY_STOP_PATIENCE = 15
+
+
+def set_seed(seed: int = SEED):
+    """pipeline:33-52 (minus the albumentations seed, which has no counterpart here)."""
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def load_state_dict_compat(model, ckpt_path):
+    """pipeline:134-141: legacy key rename, strict=False."""
+    sd = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+    new_sd = {k.replace(".W_g.", ".Wg.").replace(".W_x.", ".Wx."): v for k, v in sd.items()}
+    missing, unexpected = model.load_state_dict(new_sd, strict=False)
+    print(f"[i] loaded with {len(missing)} missing & {len(unexpected)} unexpected keys")
+    return missing, unexpected
+
+
+@torch.inference_mode()
+def evaluate(model, loader, device):
+    """pipeline:235-241: mean over batches of (1 - soft Dice loss, hard IoU).  One host
+    read at the end instead of two per batch."""
+    model.eval()
+    acc = torch.zeros(2, device=device)
+    n = 0
+    for x, y in loader:
+        x, y = x.to(device), y.to(device)
+        acc += seg_metrics(model(x), y, 0.5)
+        n += 1
+    d, i = (acc / max(n, 1)).tolist()
+    return d, i
+
+
+@torch.inference_mode()
+def predict_prob_tta(model, x):
+    """pipeline:336-338: sigmoid of the mean of logits(x) and un-flipped logits(flip(x)); numpy [H,W] of sample 0."""
+    B, _, H, W = x.shape
+    x = x.float().contiguous()
+    xf = torch.empty_like(x)
+    ops.hflip_f32(x, xf, B, H, W)
+    l = model(x)
+    lf = model(xf)
+    prob = torch.empty_like(l)
+    ops.tta_merge(l, lf, prob, B, H, W)
+    return prob[0, 0].cpu().numpy()
+
+
+def lr_at_epoch(ep, epochs, lr, stage="main"):
+    """Closed form of pipeline:303-306 (LinearLR 0.2->1 for max(1, 5%) epochs, then cosine)."""
+    warm = 0 if stage == "finetune" else max(1, int(0.05 * epochs))
+    if ep < warm:
+        return lr * (0.2 + 0.8 * ep / warm)
+    return lr * 0.5 * (1 + math.cos(math.pi * (ep - warm) / (epochs - warm)))
+
+
+class SyntheticLoader:
+    """Deterministic phantom batches (see synth.py); stands in for FetalACDataset + DataLoader (pipeline:143-170,292-295)."""
+
+    def __init__(self, n_batches, batch_size, size=IMG_SIZE, seed=SEED, device="cuda", neg_frac=0.2):
+        self.batches = []
+        for i in range(n_batches):
+            x, y = synth.make_frames(batch_size, size, seed=seed + i, neg_frac=neg_frac)
+            self.batches.append((x.to(device), y.to(device)))
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def train(args, train_loader=None, val_loader=None):
+    """pipeline:244-333.  Same optimiser / schedule / clipping / early stopping / best-checkpoint logic;
+    bf16 activations with fp32 master weights instead of fp16 autocast + GradScaler."""
+    set_seed(args.seed)
+    device = torch.device("cuda")
+    if train_loader is None:
+        n = int(getattr(args, "synthetic_batches", 0) or 0)
+        if n <= 0:
+            raise RuntimeError("no dataset reader on this machine (cv2/albumentations absent): pass loaders or --synthetic_batches N")
+        size = int(getattr(args, "img_size", IMG_SIZE))
+        train_loader = SyntheticLoader(n, args.batch_size, size, args.seed, device)
+        val_loader = SyntheticLoader(max(1, n // 10), args.batch_size, size, args.seed + 100000, device, neg_frac=0.0)
+    model = AttentionASPPUNet(base_c=args.base_c).to(device)
+    if args.stage == "finetune":
+        load_state_dict_compat(model, args.pretrained)
+        print(f"loaded pretrained {args.pretrained}")
+    opt = FusedAdamW(model, lr=args.lr, weight_decay=WEIGHT_DECAY, max_grad_norm=GRAD_CLIP)
+    tot_ep = args.epochs
+    crit = build_criterion(args, ComboLoss(), EdgeLoss())
+    out_dir = Path(args.output_dir) / ("ckpt_main" if args.stage == "main" else "ckpt_finetune")
+    out_dir.mkdir(parents=True, exist_ok=True)
+    best, best_p, noimp = 0., out_dir / f"best_{datetime.now():%Y%m%d-%H%M%S}.pt", 0
+    history = []
+    for ep in range(1, tot_ep + 1):
+        opt.param_groups[0]["lr"] = lr_at_epoch(ep - 1, tot_ep, args.lr, args.stage)
+        model.train()
+        run = torch.zeros((), device=device)
+        for x, y in train_loader:
+            x, y = x.to(device), y.to(device)
+            opt.zero_grad(set_to_none=True)
+            loss = crit(model(x), y)
+            loss.backward()
+            opt.step()
+            run += loss.detach()
+        d, i = evaluate(model, val_loader, device)
+        history.append((float(run) / max(len(train_loader), 1), d, i))
+        print(f"Epoch {ep}/{tot_ep} loss {history[-1][0]:.4f} | Dice {d:.4f} | IoU {i:.4f}")
+        if d > best:
+            best, noimp = d, 0
+            torch.save({k: v.contiguous() for k, v in model.state_dict().items()}, best_p)
+            print(f"best saved -> {best_p}")
+        else:
+            noimp += 1
+            if noimp >= EARLY_STOP_PATIENCE:
+                print("Early stop")
+                break
+    return model, history
+
+
+def get_args(argv=None):
+    """pipeline:539-550 (train / predict / calibrate flags), plus --synthetic_batches / --img_size."""
+    p = argparse.ArgumentParser("A-ASPP-UNet unified (MI355X)")
+    sp = p.add_subparsers(dest="cmd", required=True)
+    t = sp.add_parser("train")
+    t.add_argument("--stage", choices=["main", "finetune"], default="main")
+    t.add_argument("--seed", type=int, default=SEED)
+    t.add_argument("--train_dir"); t.add_argument("--neg_dir"); t.add_argument("--val_dir")
+    t.add_argument("--output_dir", default="./checkpoints"); t.add_argument("--pretrained")
+    t.add_argument("--epochs", type=int, default=120); t.add_argument("--batch_size", type=int, default=8)
+    t.add_argument("--lr", type=float, default=3e-4); t.add_argument("--base_c", type=int, default=48)
+    t.add_argument("--edge_w", type=float, default=0.05); t.add_argument("--neg_bce_w", type=float, default=0.05)
+    t.add_argument("--synthetic_batches", type=int, default=0); t.add_argument("--img_size", type=int, default=IMG_SIZE)
+    pr = sp.add_parser("predict")
+    pr.add_argument("--weights", required=True); pr.add_argument("--input_dir", required=True)
+    pr.add_argument("--out_dir", default="./preds"); pr.add_argument("--spacing_json", required=True)
+    pr.add_argument("--base_c", type=int, default=48)
+    ca = sp.add_parser("calibrate")
+    ca.add_argument("--weights", required=True); ca.add_argument("--val_dir", required=True)
+    ca.add_argument("--output_dir", default="./checkpoints"); ca.add_argument("--base_c", type=int, default=48)
+    return p.parse_args(argv)

@@ -77,7 +77,8 @@ typedef struct aau_conv_desc {
 } aau_conv_desc;
 
 /* dst[m][q] = epi( sum_{t,c} src[gather(m,t)][c] * wpk[q][t][c] )                      */
-/* wpk: bf16 [Cout][KH*KW][Cpad]; bias/scale/shift: optional fp32 [Cout] (NULL = none); */
+/* wpk: bf16 [Cout][KH*KW][Cpad]; bias/scale/shift: optional fp32 [Cout] (NULL = none;    */
+/* [Co] and indexed by co when shuffle2x2);                                             */
 /* epi(v) = relu?( (v + bias) * scale + shift ).  stats (optional):                     */
 /* fp32 [AAU_STAT_REPLICAS][2][Cout], accumulates sum and sum of squares of v (pre-     */
 /* epilogue accumulator) per output channel -- the batch statistics of the following    */

@@ -23,6 +23,8 @@ Fixtures
                        of rates other than three: the 4-rate set of BASELINE
                        config 5 cannot be executed by the reference and stays
                        "parity unpinned".)
+  g5_trained_step.npz  train-mode forward/backward (dropout p=0) of the g4 weights on the g4
+                       validation frames: logits, loss, all parameter gradients, grad norm.
   g4_trained_c8_128.npz briefly trained weights (base_c 8) with decisive masks,
                        an 8-frame validation set, logits, evaluate() Dice/IoU and
                        the evalseg integer-count Dice/IoU per frame.
@@ -177,6 +179,21 @@ def main():
         out["tta_prob0"] = ref.predict_prob_tta(net, xv[:1])
     np.savez_compressed(os.path.join(OUT, "g4_trained_c8_128.npz"), **out)
     print("g4: evaluate dice/iou", d, i, "seg dice", out["seg_dice"])
+
+    # ---------------- g5: one train-mode step at the trained weights (well conditioned gradients) ----------------
+    net.train()
+    net.bridge.project[3].p = 0.0
+    for p_ in net.parameters():
+        p_.grad = None
+    lt = net(xv)
+    loss = crit_m(lt, yv)
+    loss.backward()
+    out5 = {"train_logits": lt.detach().numpy().copy(), "loss_main": np.float64(loss.item())}
+    for k, p_ in net.named_parameters():
+        out5["grad/" + k] = p_.grad.detach().numpy().copy()
+    out5["grad_norm"] = np.float64(float(torch.nn.utils.clip_grad_norm_(net.parameters(), ref.GRAD_CLIP)))
+    np.savez_compressed(os.path.join(OUT, "g5_trained_step.npz"), **out5)
+    print("g5: loss", out5["loss_main"], "gnorm", out5["grad_norm"])
 
 
 if __name__ == "__main__":

@@ -339,3 +339,46 @@ def train_step(model, opt, crit, x, y) -> Tuple[float, float]:
     gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), GRAD_CLIP)
     opt.step()
     return loss.item(), float(gnorm)
+
+
+# --------------------------------------------------------------------------
+# bf16-storage emulation (test infrastructure for the GPU parity tests)
+# --------------------------------------------------------------------------
+class _RoundSTE(torch.autograd.Function):
+    """Round to bf16 in forward AND round the incoming gradient in backward: what happens
+    when a tensor and its gradient are each stored once as bf16 in HBM."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def emulate_bf16_storage(net: nn.Module):
+    """Make this fp32 CPU model round its tensors where the MI355X path stores bf16:
+    conv / conv-transpose outputs (and their gradients), BN+ReLU outputs, pooled maps,
+    gated skips, and the MFMA operands' weights (every conv weight except the first
+    layer, out_conv and the gates' psi, which the HIP path keeps in fp32).  The random
+    initial network is chaotic with respect to such rounding (ReLU / max-pool routing
+    flips), so GPU gradient parity is asserted against THIS model; the plain fp32 model
+    stays the reference for losses, logits and Dice."""
+    handles = []
+    round_out = lambda mod, inp, out: _RoundSTE.apply(out)
+    for name, m in net.named_modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            fp32_weights = m.in_channels % 8 != 0 or m.out_channels % 8 != 0
+            if not fp32_weights:
+                with torch.no_grad():
+                    m.weight.copy_(m.weight.to(torch.bfloat16).to(torch.float32))
+            if not (isinstance(m, nn.Conv2d) and m.out_channels % 8 != 0):
+                handles.append(m.register_forward_hook(round_out))
+        elif isinstance(m, (nn.ReLU, nn.MaxPool2d, nn.AdaptiveAvgPool2d)):
+            handles.append(m.register_forward_hook(round_out))
+        elif isinstance(m, nn.BatchNorm2d) and m.num_features > 1 and ".att." not in name:
+            handles.append(m.register_forward_hook(round_out))
+        elif isinstance(m, AttentionGate):
+            handles.append(m.register_forward_hook(round_out))
+    return handles

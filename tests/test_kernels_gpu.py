@@ -124,7 +124,7 @@ def test_convT_forward_shuffle_and_dgrad(ops):
     wp[:, 0, :Ci] = w.permute(2, 3, 1, 0).reshape(4 * Co, Ci)
     d = ops.conv_desc(N, H, W, Ci, Ci, H, W, 4 * Co, Co + 8, Cpad=cpad, shuffle2x2=1)
     wide = torch.zeros(N, 2 * H, 2 * W, Co + 8, dtype=torch.bfloat16, device="cuda")
-    ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(wp.to(torch.bfloat16)), wide[..., 8:], bias=dev(b.repeat(4)))
+    ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(wp.to(torch.bfloat16)), wide[..., 8:], bias=dev(b))
     torch.cuda.synchronize()
     assert rel_err(wide.cpu()[..., 8:], ref) < 6e-3
     # data gradient: stride-2 2x2 gather of dy, rows = cin, K = (pos, co)
