@@ -10,5 +10,6 @@ from .losses import (ComboLoss, DiceLoss, EdgeLoss, TverskyLoss, build_criterion
                      seg_metrics)
 from .optim import FusedAdamW  # noqa: F401
 from .pipeline import (EARLY_STOP_PATIENCE, GRAD_CLIP, IMG_SIZE, SEED, WEIGHT_DECAY, SyntheticLoader,  # noqa: F401
-                       evaluate, get_args, load_state_dict_compat, lr_at_epoch, predict_prob_tta, set_seed,
+                       TrainStep, evaluate, get_args, load_state_dict_compat, lr_at_epoch, predict_prob_tta, set_seed,
                        train)
+from .parallel import DataParallel, GradBucketReducer, bucket_ranges  # noqa: F401

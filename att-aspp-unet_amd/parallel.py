@@ -1,0 +1,107 @@
+"""Single-node data parallelism: one process per GPU, gradient all-reduce on RCCL over xGMI
+overlapped with the engine's backward pass.
+
+The reference has no distributed code; the semantics here are
+those of DistributedDataParallel over the reference step: every rank runs the reference
+step on its own 8 frames (per-GPU BatchNorm statistics, like eight bs=8 replicas), the
+gradients are averaged, and every rank applies the identical clip + AdamW update.
+
+The flat gradient buffer is laid out in registration order (d1..d4, bridge, u4..u1,
+out_conv) and the backward pass finishes it from the back, so buckets are contiguous
+slices that become final at known points of the recorded backward list ("marks").  Each
+mark enqueues one all-reduce (async: RCCL runs it on its own stream behind an event on
+the compute stream) while the remaining backward kernels keep the CUs busy.  xGMI is
+point-to-point: a few large buckets (here 4: <=46 MB) beat many small ones.  The 1/world
+factor is folded into the optimiser's unscale factor, so no extra pass touches the grads.
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+import torch.distributed as dist
+
+# mark fired by the engine after the backward of a block -> parameter-name prefixes whose grads are then final
+BUCKET_PLAN = (
+    ("u3", ("u3.", "u2.", "u1.", "out_conv.")),
+    ("u4", ("u4.",)),
+    ("bridge", ("bridge.",)),
+    ("d1", ("d1.", "d2.", "d3.", "d4.")),
+)
+
+
+def bucket_ranges(names: Sequence[str], offs: dict, numels: dict, total: int, align: int = 64):
+    """-> {mark: (begin, end)} contiguous element ranges of the flat buffer, covering it exactly once."""
+    out = {}
+    for mark, prefixes in BUCKET_PLAN:
+        sel = [n for n in names if n.startswith(prefixes)]
+        if not sel:
+            continue
+        b = min(offs[n] for n in sel)
+        e = max(offs[n] + (numels[n] + align - 1) // align * align for n in sel)
+        out[mark] = (b, min(e, total))
+    # sanity: disjoint and covering
+    spans = sorted(out.values())
+    assert spans[0][0] == 0 and spans[-1][1] == total, spans
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0, spans
+    return out
+
+
+class GradBucketReducer:
+    """Launches one async all-reduce per bucket when its mark fires; ``finish()`` makes the current
+    stream wait for all of them.  Works on any flat tensor / backend (RCCL on GPU, gloo on CPU)."""
+
+    def __init__(self, flat: torch.Tensor, ranges: dict, group=None):
+        self.flat, self.ranges, self.group = flat, ranges, group
+        self.works = []
+        self.fired = []
+
+    def on_mark(self, mark: str):
+        r = self.ranges.get(mark)
+        if r is None:
+            return
+        self.fired.append(mark)
+        self.works.append(dist.all_reduce(self.flat[r[0]:r[1]], op=dist.ReduceOp.SUM, group=self.group,
+                                          async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        missing = set(self.ranges) - set(self.fired)
+        self.works, self.fired = [], []
+        if missing:
+            raise RuntimeError(f"gradient buckets never reduced: {sorted(missing)}")
+
+
+class DataParallel:
+    """Wraps an AttentionASPPUNet for DP training.  Usage:
+        dp = DataParallel(model); ... loss.backward() (or TrainStep) ...; dp.finish(); opt.step(inv_scale=dp.inv_scale)
+    """
+
+    def __init__(self, model, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.model, self.group = model, group
+        self.world = dist.get_world_size(group)
+        self.inv_scale = 1.0 / self.world
+        self.reducer = None
+        model.engine.bucket_cb = self._on_mark
+        # identical starting weights on every rank
+        st = model.engine.store
+        tensors = [st.flat] if st is not None else [p.data for p in model.parameters()]
+        for t in tensors + [b.data for b in model.buffers()]:
+            dist.broadcast(t, src=0, group=group)
+
+    def _ensure(self):
+        st = self.model.engine.store
+        if self.reducer is None or self.reducer.flat is not st.gflat:
+            numels = {n: p.numel() for n, p in zip(st.names, st.params)}
+            self.reducer = GradBucketReducer(st.gflat, bucket_ranges(st.names, st.offs, numels, st.total), self.group)
+        return self.reducer
+
+    def _on_mark(self, mark):
+        self._ensure().on_mark(mark)
+
+    def finish(self):
+        self._ensure().finish()

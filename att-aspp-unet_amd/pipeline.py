@@ -148,6 +148,37 @@ def train(args, train_loader=None, val_loader=None):
     return model, history
 
 
+class TrainStep:
+    """The reference inner loop body (pipeline:319-324) as ONE fused call with no autograd graph,
+    no allocator traffic and no host synchronisation: forward plan -> fused criterion (writes
+    d(loss)/d(logits) straight into the plan) -> backward plan (-> bucketed all-reduce when
+    data-parallel) -> clip + AdamW.  ``loss`` stays on the device."""
+
+    def __init__(self, model, opt, args, dp=None):
+        self.model, self.opt, self.dp = model, opt, dp
+        self.finetune = args.stage == "finetune"
+        self.neg_w, self.edge_w = float(args.neg_bce_w), max(float(args.edge_w), 0.0)
+        self.sums = self.loss = None
+
+    def __call__(self, x, y):
+        m = self.model
+        assert m.training, "TrainStep needs model.train()"
+        plan = m._plan_for(x)
+        B, _, H, W = x.shape
+        if self.sums is None or self.sums.shape[0] != B:
+            self.sums = torch.zeros(B, 8, device=x.device)
+            self.loss = torch.zeros(4, device=x.device)
+        logits = plan.run_forward(x)
+        ops.criterion(logits, y, self.sums, self.loss, plan.dlogits, B, H, W, self.finetune, self.neg_w, self.edge_w)
+        plan.run_backward(None)
+        inv = 1.0
+        if self.dp is not None:
+            self.dp.finish()
+            inv = self.dp.inv_scale
+        self.opt.step(inv_scale=inv)
+        return self.loss[0]
+
+
 def get_args(argv=None):
     """pipeline:539-550 (train / predict / calibrate flags), plus --synthetic_batches / --img_size."""
     p = argparse.ArgumentParser("A-ASPP-UNet unified (MI355X)")

@@ -1,0 +1,213 @@
+"""Headline benchmark: images/sec of the full train step (forward + criterion + backward +
+[gradient all-reduce] + clip + AdamW) of Attention-ASPP-UNet, base_c 48, 1x512x512 frames,
+batch 8 per GPU, bf16 activations / fp32 master weights, synthetic ultrasound phantoms.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
+  roofline     dominant kernel family = the MFMA implicit-GEMM convolutions (forward, data- and
+               weight-gradient launches): algorithmic conv FLOPs of the step (680.05 GFLOP/image,
+               BASELINE.md section 2) / summed kernel time of those launches, measured with HIP
+               events around every launch on the launch stream in a second pass of the same steps.
+  cpu_baseline the CPU oracle (oracle/ref_cpu.py, an ATen fp32 restatement of the reference step)
+               timed on this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_GFLOP_PER_IMAGE = {48: 226.76, 32: 100.84, 16: 25.25}
+PEAK_BF16_TFLOPS = 2500.0                                     # MI355X dense bf16 MFMA (guide, spec)
+
+
+def train_gflop_per_image(base_c, size):
+    f = FWD_GFLOP_PER_IMAGE.get(base_c, 226.76 * (base_c / 48.0) ** 2) * (size / 512.0) ** 2
+    first_dgrad = 2 * 9 * base_c * size * size / 1e9           # no input gradient for the first layer
+    return 3 * f - first_dgrad
+
+
+def host_cores():
+    """CPU share actually available to this process (cgroup quota / affinity), not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("AAU_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(base_c, size, seconds_budget=25.0):
+    """Time the CPU oracle's train step on a bounded sample of the same workload."""
+    from argparse import Namespace
+    from oracle import ref_cpu as O
+    from att_aspp_unet_amd import synth
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    torch.manual_seed(2025)
+    net = O.AttentionASPPUNet(base_c=base_c)
+    net.train()
+    opt = O.make_optimizer(net, 3e-4)
+    crit = O.build_criterion(Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05), O.ComboLoss(), O.EdgeLoss())
+    bs = 2
+    x, y = synth.make_frames(bs, size, seed=2025)
+    t0 = time.perf_counter()
+    O.train_step(net, opt, crit, x, y)                          # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    n = max(1, min(3, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        O.train_step(net, opt, crit, x, y)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": bs / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} timed + 1 warm-up fp32 train steps of the CPU oracle at batch {bs}, {size}x{size}, "
+                      f"base_c {base_c} (same step, smaller batch; BN needs >= 2)",
+            "sec_per_step": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--base_c", type=int, default=48)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=8, help="per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("AAU_BENCH_GRAPH", "1")),
+                    help="replay the step as one hipGraph when possible")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import att_aspp_unet_amd as A
+    from att_aspp_unet_amd import _abi, synth
+    from argparse import Namespace
+    args = Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05)
+    torch.manual_seed(2025)
+    model = A.AttentionASPPUNet(base_c=a.base_c).to(dev).train()
+    dp = A.DataParallel(model) if world > 1 else None
+    opt = A.FusedAdamW(model, lr=3e-4, weight_decay=A.WEIGHT_DECAY, max_grad_norm=A.GRAD_CLIP)
+    step = A.TrainStep(model, opt, args, dp)
+    x, y = synth.make_frames(a.batch, a.size, seed=2025 + rank)     # weak scaling: 8 new frames per rank
+    x, y = x.to(dev), y.to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run = step
+    graphed = False
+    for i in range(a.warmup):
+        loss = run(x, y)
+    barrier()
+    if a.graph and world == 1:
+        try:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step(x, y)
+                with torch.cuda.graph(g, stream=s):
+                    gl = step(x, y)
+            torch.cuda.current_stream().wait_stream(s)
+            g.replay()
+            torch.cuda.synchronize()
+            run = lambda *_: (g.replay(), gl)[1]
+            graphed = True
+        except Exception as e:  # capture is an optimisation; the eager replay list is the same work
+            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing the eager launch list",
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            run = step
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = run(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_val = float(loss.item())
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        # second pass of the same steps with every launch bracketed by HIP events on its stream
+        nprof = min(a.steps, 5)
+        _abi.prof_enable(True)
+        for i in range(nprof):
+            step(x, y)
+        torch.cuda.synchronize()
+        _abi.prof_enable(False)
+        prof = _abi.prof_collect()
+        conv_ms = (prof["igemm"]["ms"] + prof["wgrad"]["ms"]) / nprof
+        alg = train_gflop_per_image(a.base_c, a.size) * a.batch * 1e9
+        achieved = alg / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                "kernel": "igemm_kernel + wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad)",
+                "launches_per_step": (prof["igemm"]["launches"] + prof["wgrad"]["launches"]) // nprof,
+                "avg_launch_ms": conv_ms / max(1, (prof["igemm"]["launches"] + prof["wgrad"]["launches"]) // nprof),
+                "algorithmic_flops_per_step": alg,
+                "ms_per_step_by_family": {k: v["ms"] / nprof for k, v in prof.items()},
+                "counted_flops_per_step": {k: v["flops"] / nprof for k, v in prof.items()},
+                "whole_step_frac": alg / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.base_c, a.size)
+
+    if rank == 0:
+        imgs = a.batch * world * a.steps
+        out = {
+            "metric": "images/sec (train step) 1x512x512 bs=8/GPU",
+            "value": imgs / dt, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Attention-ASPP-UNet full train step (fwd+Dice/BCE/edge loss+bwd+clip+AdamW), "
+                                   f"base_c {a.base_c}, 1x{a.size}x{a.size}, batch {a.batch}/GPU, bf16 activations, "
+                                   f"fp32 master weights" + (", RCCL grad all-reduce overlapped with backward" if world > 1 else ""),
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
+                       "final_loss": loss_val},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
