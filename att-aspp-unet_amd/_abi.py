@@ -56,6 +56,7 @@ _SIGS = {
     "aau_bn_finalize": [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
     "aau_bn_fold_eval": [P, P, P, P, P, P, I, F, P],
     "aau_bn_act": [P, I, P, I, P, P, L, I, I, L, F, U64, P],
+    "aau_bn_act_pool": [P, I, P, I, P, I, P, P, I, I, I, I, P],
     "aau_maxpool2": [P, I, P, I, I, I, I, I, P],
     "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, U64, P],
     "aau_bn_bwd_apply": [P, I, P, I, P, P, P, P, P, P, L, I, P],
@@ -68,8 +69,8 @@ _SIGS = {
     "aau_gate_bwd2": [P] * 23 + [L, I, P],
     "aau_gate_bwd3": [P] * 17 + [L, I, P],
     "aau_outconv_fwd": [P, I, P, P, P, L, I, P],
-    "aau_outconv_bwd": [P, I, P, P, P, I, P, P, L, I, P],
-    "aau_colsum": [P, I, P, L, I, P],
+    "aau_outconv_bwd": [P, I, P, P, P, I, P, P, P, L, I, P],
+    "aau_colsum": [P, I, P, P, L, I, P],
     "aau_criterion": [P, P, P, P, P, I, I, I, I, F, F, F, P],
     "aau_seg_metrics": [P, P, P, P, I, I, I, F, P],
     "aau_grad_sqnorm": [P, L, F, P, P],

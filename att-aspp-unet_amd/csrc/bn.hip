@@ -128,6 +128,40 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const unsigned short* y, 
     }
 }
 
+// y = relu(z*scale+shift) and p = maxpool2x2(y) in one pass: one thread per 2x2 window and channel group
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const unsigned short* z, int zp, unsigned short* y, int yp,
+                                                          unsigned short* p, int pp, const float* scale,
+                                                          const float* shift, int N, int H, int W, int C) {
+    const int CG = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Ho * Wo * CG;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
+        const int64_t mo = v / CG;
+        const int c = (int)(v - mo * CG) * 8;
+        const int xo = (int)(mo % Wo);
+        const int64_t t = mo / Wo;
+        const int yo = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int64_t p00 = ((int64_t)n * H + 2 * yo) * W + 2 * xo;
+        const int64_t pix[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+        float sc[8], sh[8], best[8];
+        ldf8(scale + c, sc);
+        ldf8(shift + c, sh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[8];
+            unpack8(ld16(z + pix[k] * zp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+            const u32x4 pk = pack8(f);
+            st16(y + pix[k] * yp + c, pk);
+            unpack8(pk, f);  // pool the bf16 values that were stored, as the separate kernel does
+#pragma unroll
+            for (int j = 0; j < 8; ++j) best[j] = k == 0 ? f[j] : fmaxf(best[j], f[j]);
+        }
+        st16(p + mo * pp + c, pack8(best));
+    }
+}
+
 // ---- backward pass 1: masked gradient + per-channel sums ----
 // POOL = true: one thread per 2x2 window (H, W even) so the max-pool routing needs no re-reads.
 template <bool POOL>
@@ -316,6 +350,18 @@ extern "C" int aau_bn_act(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pit
     hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, z, z_pitch, y,
                        y_pitch, scale, shift, M, C, relu, bcast_hw, drop_p, drop_seed);
     return check_launch("aau_bn_act");
+}
+
+extern "C" int aau_bn_act_pool(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pitch, aau_bf16* p, int p_pitch,
+                               const float* scale, const float* shift, int N, int H, int W, int C, void* stream) {
+    AAU_REQUIRE(z && y && p && scale && shift && N > 0, "aau_bn_act_pool: bad args");
+    AAU_REQUIRE(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "aau_bn_act_pool: H=%d W=%d must be even", H, W);
+    CHK_C("aau_bn_act_pool", C);
+    AAU_REQUIRE(z_pitch % 8 == 0 && y_pitch % 8 == 0 && p_pitch % 8 == 0, "aau_bn_act_pool: pitches must be multiples of 8");
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_act_pool_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8), 256 * 16)), dim3(256), 0,
+                       (hipStream_t)stream, z, z_pitch, y, y_pitch, p, p_pitch, scale, shift, N, H, W, C);
+    return check_launch("aau_bn_act_pool");
 }
 
 extern "C" int aau_maxpool2(const aau_bf16* y, int y_pitch, aau_bf16* p, int p_pitch, int N, int H, int W, int C,

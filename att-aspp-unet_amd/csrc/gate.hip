@@ -50,39 +50,47 @@ __device__ __forceinline__ void ldf8g(const float* p, float f[8]) {
     for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
 }
 
-// one thread per pixel
+// channel-group threads (8 channels each); the per-pixel dot product is combined through LDS
 __global__ __launch_bounds__(256) void gate_psi_kernel(const unsigned short* zg, const unsigned short* zx,
                                                        const float* sg, const float* hg, const float* sx,
                                                        const float* hx, const float* wpsi, float* psi_pre,
-                                                       float* stats, int64_t M, int F) {
-    extern __shared__ float sm[];  // [5][F]
-    float* p_sg = sm; float* p_hg = sm + F; float* p_sx = sm + 2 * F; float* p_hx = sm + 3 * F; float* p_w = sm + 4 * F;
+                                                       float* stats, int64_t M, int F, int64_t ppb) {
+    __shared__ float part[256];
     __shared__ float s4[4];
-    for (int i = threadIdx.x; i < F; i += 256) {
-        p_sg[i] = sg[i]; p_hg[i] = hg[i]; p_sx[i] = sx[i]; p_hx[i] = hx[i]; p_w[i] = wpsi[i];
-    }
-    __syncthreads();
+    const CGMap3 mp(F);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    const bool active = tid < mp.T;
+    float v_sg[8], v_hg[8], v_sx[8], v_hx[8], v_w[8];
+    if (active) { ldf8g(sg + c, v_sg); ldf8g(hg + c, v_hg); ldf8g(sx + c, v_sx); ldf8g(hx + c, v_hx); ldf8g(wpsi + c, v_w); }
     float t1 = 0.f, t2 = 0.f;
-    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    for (int64_t mb = m0; mb < m1; mb += mp.PL) {
+        const int64_t m = mb + pl;
         float acc = 0.f;
-        for (int f = 0; f < F; f += 8) {
+        if (active && m < m1) {
             float a[8], b[8];
-            unpack8(*(const u32x4*)(zg + m * F + f), a);
-            unpack8(*(const u32x4*)(zx + m * F + f), b);
+            unpack8(*(const u32x4*)(zg + m * F + c), a);
+            unpack8(*(const u32x4*)(zx + m * F + c), b);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float s = fmaxf(a[j] * p_sg[f + j] + p_hg[f + j] + b[j] * p_sx[f + j] + p_hx[f + j], 0.f);
-                acc += s * p_w[f + j];
-            }
+            for (int j = 0; j < 8; ++j)
+                acc += fmaxf(a[j] * v_sg[j] + v_hg[j] + b[j] * v_sx[j] + v_hx[j], 0.f) * v_w[j];
         }
-        psi_pre[m] = acc;
-        t1 += acc;
-        t2 += acc * acc;
+        part[tid] = acc;
+        __syncthreads();
+        if (active && cg == 0 && m < m1) {
+            float tot = 0.f;
+            for (int k = 0; k < mp.CG; ++k) tot += part[tid + k];
+            psi_pre[m] = tot;
+            t1 += tot;
+            t2 += tot * tot;
+        }
+        __syncthreads();
     }
     if (stats) {
         const float a = block_sum1(t1, s4);
         const float b = block_sum1(t2, s4);
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             float* r = stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2;
             atomicAdd(r, a);
             atomicAdd(r + 1, b);
@@ -109,19 +117,26 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const unsigned short* x
     }
 }
 
-// one thread per pixel: dx = dout*alpha ; dq = <dout, x> * alpha(1-alpha) ; red1 += (dq, dq*psihat)
+// channel-group threads: dx = dout*alpha ; dq = <dout, x> * alpha(1-alpha) ; red1 += (dq, dq*psihat)
 __global__ __launch_bounds__(256) void gate_bwd1_kernel(const unsigned short* dout, int dop, const unsigned short* x,
                                                         int xp, const float* alpha, const float* psi_pre,
                                                         const float* mean1, const float* invstd1,
                                                         unsigned short* dx, int dxp, float* dq, float* red1,
-                                                        int64_t M, int C) {
+                                                        int64_t M, int C, int64_t ppb) {
+    __shared__ float part[256];
     __shared__ float s4[4];
+    const CGMap3 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    const bool active = tid < mp.T;
     const float mu = mean1[0], is = invstd1[0];
     float t1 = 0.f, t2 = 0.f;
-    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
-        const float a = alpha[m];
-        float dot = 0.f;
-        for (int c = 0; c < C; c += 8) {
+    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    for (int64_t mb = m0; mb < m1; mb += mp.PL) {
+        const int64_t m = mb + pl;
+        float dot = 0.f, a = 0.f;
+        if (active && m < m1) {
+            a = alpha[m];
             float g[8], xv[8];
             unpack8(*(const u32x4*)(dout + m * dop + c), g);
             unpack8(*(const u32x4*)(x + m * xp + c), xv);
@@ -129,14 +144,21 @@ __global__ __launch_bounds__(256) void gate_bwd1_kernel(const unsigned short* do
             for (int j = 0; j < 8; ++j) { dot += g[j] * xv[j]; g[j] *= a; }
             *(u32x4*)(dx + m * dxp + c) = pack8(g);
         }
-        const float q = dot * a * (1.f - a);
-        dq[m] = q;
-        t1 += q;
-        t2 += q * (psi_pre[m] - mu) * is;
+        part[tid] = dot;
+        __syncthreads();
+        if (active && cg == 0 && m < m1) {
+            float tot = 0.f;
+            for (int k = 0; k < mp.CG; ++k) tot += part[tid + k];
+            const float q = tot * a * (1.f - a);
+            dq[m] = q;
+            t1 += q;
+            t2 += q * (psi_pre[m] - mu) * is;
+        }
+        __syncthreads();
     }
     const float a = block_sum1(t1, s4);
     const float b = block_sum1(t2, s4);
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         float* r = red1 + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2;
         atomicAdd(r, a);
         atomicAdd(r + 1, b);
@@ -279,8 +301,14 @@ extern "C" int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float*
     AAU_REQUIRE(zg && zx && sg && hg && sx && hx && wpsi && psi_pre && M > 0, "aau_gate_psi: bad args");
     CHK_F("aau_gate_psi", F);
     ProfScope prof(2, 2.0 * M * F, (hipStream_t)stream);
-    hipLaunchKernelGGL(gate_psi_kernel, dim3(grid1(M)), dim3(256), 5 * F * sizeof(float), (hipStream_t)stream, zg, zx,
-                       sg, hg, sx, hx, wpsi, psi_pre, stats, M, F);
+    const CGMap3 mp(F);
+    int64_t b = (M + (int64_t)mp.PL * 8 - 1) / ((int64_t)mp.PL * 8);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    const int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
+    b = (M + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gate_psi_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, zg, zx, sg, hg, sx, hx,
+                       wpsi, psi_pre, stats, M, F, ppb);
     return check_launch("aau_gate_psi");
 }
 
@@ -304,8 +332,14 @@ extern "C" int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf1
     CHK_F("aau_gate_bwd1", C);
     AAU_REQUIRE(dout_pitch % 8 == 0 && x_pitch % 8 == 0 && dx_pitch % 8 == 0, "aau_gate_bwd1: pitch");
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(gate_bwd1_kernel, dim3(grid1(M)), dim3(256), 0, (hipStream_t)stream, dout, dout_pitch, x,
-                       x_pitch, alpha, psi_pre, mean1, invstd1, dx, dx_pitch, dq, red1, M, C);
+    const CGMap3 mp(C);
+    int64_t b = (M + (int64_t)mp.PL * 8 - 1) / ((int64_t)mp.PL * 8);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    const int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
+    b = (M + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gate_bwd1_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dout, dout_pitch, x,
+                       x_pitch, alpha, psi_pre, mean1, invstd1, dx, dx_pitch, dq, red1, M, C, ppb);
     return check_launch("aau_gate_bwd1");
 }
 

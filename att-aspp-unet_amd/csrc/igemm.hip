@@ -43,6 +43,8 @@ struct IgemmArgs {
     float* stats;
     int M;
     int nchunk;  // Cpad / BK
+    unsigned src_bytes;  // extent of the gather source (buffer descriptor range; out-of-range reads return 0)
+    unsigned wpk_bytes;
 };
 
 template <int BK, int BQ>
@@ -80,12 +82,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int q0 = tq * BQ;
     const int m0 = tp * BP;
 
-    const unsigned short* zero = (const unsigned short*)g_zero_page;
     const int HoWo = d.Ho * d.Wo;
+    constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor range: the load returns zeros
+
+    // Buffer descriptors (wave-uniform): hardware range check = free zero fill for padding taps,
+    // rows past M and channels past Cin; 32-bit offsets keep the per-load address math to ~1 VALU op.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
 
     // ---- per-thread row bookkeeping for the activation gather ----
     int pix0[NA];   // n*H*W
-    int yx0[NA];    // (y0 << 16) | (x0 & 0xffff), y0/x0 = out*stride - pad; y0 = -32768 marks "row past M"
+    int yx0[NA];    // (y0 << 16) | (x0 & 0xffff), y0/x0 = out*stride - pad; 0x80000000 marks "row past M"
     const int slot = lane % SLOTS;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -107,16 +114,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     int lcA[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) lcA[i] = swz<BK>((i * 4 + wave) * RPI + lane / SLOTS, slot);
-    int lcW[NW];
-    int qrow[NW];
+    const int T = d.KH * d.KW;
+    unsigned wbase[NW];  // byte offset of (row q, tap 0, this lane's logical chunk) in the packed weights
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int row = (j * 4 + wave) * RPI + lane / SLOTS;
-        lcW[j] = swz<BK>(row, slot);
-        qrow[j] = (row < BQ && q0 + row < d.Cout) ? (q0 + row) : -1;
+        const int lc = swz<BK>(row, slot);
+        wbase[j] = (row < BQ && q0 + row < d.Cout) ? (unsigned)(((q0 + row) * T * d.Cpad + lc * 8) * 2) : OOB;
     }
-
-    const int T = d.KH * d.KW;
+    // channel tail: in the last chunk of a tap, chunks that start at or beyond Cin read zeros
+    const int tail_c0 = (a.nchunk - 1) * BK;
+    bool tail_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) tail_ok[i] = tail_c0 + lcA[i] * 8 < d.Cin;
+    const bool has_tail = d.Cpad != d.Cin;
 
     // ---- active taps: a tap whose every row of this tile is out of the image is skipped ----
     unsigned tapmask = (T >= 32) ? 0xffffffffu : ((1u << T) - 1u);
@@ -142,35 +153,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         if (tapmask == 0) tapmask = 1;  // still run one (all-zero) step so the epilogue sees zeros
     }
 
-    const unsigned short* rowptr[NA];
+    unsigned abase[NA];  // byte offset of (gathered pixel, this lane's logical chunk) for the current tap
     auto set_tap = [&](int tap) {
         const int dy = (tap / d.KW) * d.dil, dx = (tap % d.KW) * d.dil;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int y = (yx0[i] >> 16) + dy, x = (short)(yx0[i] & 0xffff) + dx;
             const bool ok = (yx0[i] != (int)0x80000000) && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
-            rowptr[i] = ok ? a.src + (int64_t)(pix0[i] + y * d.W + x) * d.src_pitch : nullptr;
+            abase[i] = ok ? (unsigned)(((pix0[i] + y * d.W + x) * d.src_pitch + lcA[i] * 8) * 2) : OOB;
         }
     };
 
     auto stage = [&](int buf, int tap, int chunk) {
-        const int c0 = chunk * BK;
+        const int soffA = chunk * BK * 2;                      // scalar byte offsets
+        const int soffW = (tap * d.Cpad + chunk * BK) * 2;
+        const bool last = has_tail && chunk == a.nchunk - 1;   // uniform
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int ch = c0 + lcA[i] * 8;
-            const unsigned short* g = (rowptr[i] != nullptr && ch < d.Cin) ? rowptr[i] + ch : zero;
-            unsigned short* l = sA(buf) + (i * 4 + wave) * RPI * BK;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, 0, 0);
+            const unsigned v = (last && !tail_ok[i]) ? OOB : abase[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA(buf) + (i * 4 + wave) * RPI * BK), 16, (int)v,
+                                                     soffA, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            if ((j * 4 + wave) * RPI < BQ) {  // wave-uniform
-                const int ch = c0 + lcW[j] * 8;
-                const unsigned short* g = (qrow[j] >= 0)
-                    ? a.wpk + ((int64_t)qrow[j] * T + tap) * d.Cpad + ch : zero;
-                unsigned short* l = sW(buf) + (j * 4 + wave) * RPI * BK;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, 0, 0);
-            }
+            if ((j * 4 + wave) * RPI < BQ)  // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(sW(buf) + (j * 4 + wave) * RPI * BK), 16,
+                                                         (int)wbase[j], soffW, 0, 0);
         }
     };
 
@@ -370,6 +378,13 @@ extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const
     a.d = *d;
     a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
     a.M = d->N * d->Ho * d->Wo;
+    const int64_t src_bytes = (((int64_t)d->N * d->H * d->W - 1) * d->src_pitch + d->Cin) * 2;
+    const int64_t wpk_bytes = (int64_t)d->Cout * d->KH * d->KW * d->Cpad * 2;
+    AAU_REQUIRE(src_bytes < 0x7fffffff && wpk_bytes < 0x7fffffff,
+                "aau_conv_igemm: source (%lld B) / packed weights (%lld B) must stay below 2 GiB", (long long)src_bytes,
+                (long long)wpk_bytes);
+    a.src_bytes = (unsigned)src_bytes;
+    a.wpk_bytes = (unsigned)wpk_bytes;
     const bool bk64 = (d->Cpad % 64 == 0);
     a.nchunk = d->Cpad / (bk64 ? 64 : 32);
     const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;

@@ -16,6 +16,7 @@ namespace aau {
 // sums layout per sample: 0 sum t, 1 sum p, 2 sum p*t, 3 sum bce, 4 sum |gp-gt|, 5 sum pbin, 6 sum pbin*t
 constexpr int NS = 8;
 constexpr int TILE = 16;
+constexpr int NREP = AAU_STAT_REPLICAS;  // sums workspace = [NREP][B][NS]: same-address atomics are spread over replicas
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // numerically stable BCE-with-logits element: max(x,0) - x*t + log1p(exp(-|x|))
@@ -73,8 +74,18 @@ __global__ __launch_bounds__(256) void crit_reduce_kernel(const float* logits, c
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         const float s = block_sum(v[k], s4);
-        if (tid == 0 && s != 0.f) atomicAdd(sums + b * NS + k, s);
+        if (tid == 0 && s != 0.f)
+            atomicAdd(sums + ((size_t)((blockIdx.x + blockIdx.y) % NREP) * gridDim.z + b) * NS + k, s);
     }
+}
+
+// collapse the replicas into replica 0 so that the consumers read one [B][NS] table
+__global__ void crit_fold_kernel(float* sums, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * NS) return;
+    float a = 0.f;
+    for (int r = 0; r < NREP; ++r) a += sums[(size_t)r * B * NS + i];
+    sums[i] = a;
 }
 
 struct CritTerms {  // per-launch scalars derived from the per-sample sums
@@ -211,10 +222,11 @@ extern "C" int aau_criterion(const float* logits, const float* targets, float* s
                 "aau_criterion: bad args");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(3, 0, s);
-    hipMemsetAsync(sums, 0, (size_t)B * NS * sizeof(float), s);
+    hipMemsetAsync(sums, 0, (size_t)NREP * B * NS * sizeof(float), s);
     dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
     hipLaunchKernelGGL(crit_reduce_kernel, grid, dim3(256), 0, s, logits, targets, sums, H, W, 0.f,
                        edge_w > 0.f ? 1 : 0);
+    hipLaunchKernelGGL(crit_fold_kernel, dim3((B * NS + 255) / 256), dim3(256), 0, s, sums, B);
     hipLaunchKernelGGL(crit_loss_kernel, dim3(1), dim3(64), 0, s, sums, loss_out, B, (float)H * (float)W, finetune,
                        neg_bce_w, edge_w);
     if (dlogits)
@@ -230,10 +242,11 @@ extern "C" int aau_seg_metrics(const float* logits, const float* targets, float*
     AAU_REQUIRE(thr > 0.f && thr < 1.f, "aau_seg_metrics: thr=%f must be in (0,1)", thr);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(3, 0, s);
-    hipMemsetAsync(sums, 0, (size_t)B * NS * sizeof(float), s);
+    hipMemsetAsync(sums, 0, (size_t)NREP * B * NS * sizeof(float), s);
     dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
     const float thr_logit = logf(thr / (1.f - thr));  // sigmoid(l) > thr  <=>  l > logit(thr)
     hipLaunchKernelGGL(crit_reduce_kernel, grid, dim3(256), 0, s, logits, targets, sums, H, W, thr_logit, 0);
+    hipLaunchKernelGGL(crit_fold_kernel, dim3((B * NS + 255) / 256), dim3(256), 0, s, sums, B);
     hipLaunchKernelGGL(seg_metrics_kernel, dim3(1), dim3(64), 0, s, sums, metrics_out, B);
     return check_launch("aau_seg_metrics");
 }

@@ -57,29 +57,46 @@ __global__ void step_inc_kernel(const float* norm_ws, int64_t* step_dev) {
 }
 
 // packed[dst_off + (r*T + t)*Cpad + c] = bf16(flat[src_off + r1*s_r + r2*s_r2 + tt*s_t + c*s_c]) (0 for c >= C)
+// One thread produces 8 consecutive packed channels (one 16-B store).  The thread -> (row, tap, channel
+// group) map follows the SOURCE's contiguous axis so that the fp32 reads coalesce: channel-fastest when
+// s_c == 1 (two 16-B loads per thread), row-fastest otherwise (the transposed data-gradient operands).
 __global__ __launch_bounds__(256) void pack_kernel(const float* flat, unsigned short* packed,
                                                    const aau_pack_entry* table, int n_entries) {
-    // locate this block's entry (table is short: linear scan on the scalar unit)
     int e = 0;
     const int64_t blk = blockIdx.x;
     while (e + 1 < n_entries && table[e + 1].blk_begin <= blk) ++e;
     const aau_pack_entry ent = table[e];
-    const int64_t total = (int64_t)ent.R * ent.T * ent.Cpad;
-    const int64_t i = (blk - ent.blk_begin) * 256 + threadIdx.x;
+    const unsigned C8 = ent.Cpad >> 3;
+    const unsigned total = (unsigned)ent.R * ent.T * C8;
+    const unsigned i = (unsigned)(blk - ent.blk_begin) * 256u + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % ent.Cpad);
-    const int64_t rt = i / ent.Cpad;
-    const int t = (int)(rt % ent.T);
-    const int r = (int)(rt / ent.T);
-    float val = 0.f;
-    if (c < ent.C) {
-        const int tt = ent.t_flip ? ent.T - 1 - t : t;
-        int64_t off = ent.src_off + (int64_t)tt * ent.s_t + (int64_t)c * ent.s_c;
-        if (ent.R2 > 0) off += (int64_t)(r / ent.R2) * ent.s_r + (int64_t)(r % ent.R2) * ent.s_r2;
-        else off += (int64_t)r * ent.s_r;
-        val = flat[off];
+    unsigned r, t, c8;
+    if (ent.s_c == 1) {
+        c8 = i % C8;
+        const unsigned rt = i / C8;
+        t = rt % ent.T;
+        r = rt / ent.T;
+    } else {
+        r = i % ent.R;
+        const unsigned ct = i / ent.R;
+        t = ct % ent.T;
+        c8 = ct / ent.T;
     }
-    packed[ent.dst_off + i] = f2bf(val);
+    const unsigned tt = ent.t_flip ? ent.T - 1 - t : t;
+    int64_t off = ent.src_off + (int64_t)tt * ent.s_t;
+    if (ent.R2 > 0) off += (int64_t)(r / ent.R2) * ent.s_r + (int64_t)(r % ent.R2) * ent.s_r2;
+    else off += (int64_t)r * ent.s_r;
+    const int c0 = c8 * 8;
+    float v[8];
+    if (ent.s_c == 1 && c0 + 8 <= ent.C && ((off + c0) & 3) == 0) {
+        const f32x4 a = *(const f32x4*)(flat + off + c0), b = *(const f32x4*)(flat + off + c0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (c0 + j < ent.C) ? flat[off + (int64_t)(c0 + j) * ent.s_c] : 0.f;
+    }
+    *(u32x4*)(packed + ent.dst_off + ((int64_t)r * ent.T + t) * ent.Cpad + c0) = pack8(v);
 }
 
 }  // namespace aau

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const unsigned short* 
 
 // ---- out_conv backward: dy = dl*w ; dw += sum dl*y ; db += sum dl ----
 __global__ __launch_bounds__(256) void outconv_bwd_kernel(const unsigned short* y, int yp, const float* dl,
-                                                          const float* w, unsigned short* dy, int dyp, float* dw,
-                                                          float* db, int64_t M, int C, int64_t ppb) {
+                                                          const float* w, unsigned short* dy, int dyp, float* ws,
+                                                          int64_t M, int C, int64_t ppb) {
     __shared__ float sred[256 * 8];
     const CGMap2 mp(C);
     const int tid = threadIdx.x;
@@ -182,13 +182,24 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const unsigned short* 
             *(u32x4*)(dy + m * dyp + c) = pack8(o);
         }
     }
+    float* r = ws + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * (C + 8);
     block_sum8b(s, sred, mp, tid);
     if (tid < mp.CG) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(dw + c + j, s[j]);
+        for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s[j]);
     }
     block_sum8b(sb, sred, mp, tid);
-    if (tid == 0 && db) atomicAdd(db, sb[0]);
+    if (tid == 0) atomicAdd(r + C, sb[0]);
+}
+
+// out[i] += sum over replicas of ws[r][i] (i < n); optionally a second target for element n (bias)
+__global__ void fold_replicas_kernel(const float* ws, int stride, float* out, int n, float* out2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n || (i == n && out2 == nullptr)) return;
+    float a = 0.f;
+    for (int r = 0; r < AAU_STAT_REPLICAS; ++r) a += ws[(size_t)r * stride + i];
+    if (i < n) out[i] += a;
+    else out2[0] += a;
 }
 
 // ---- out[n][c] = alpha * sum_p src[n][p][c]; one block per (image, slab of pixels) ----
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const unsigned short* dpoo
 }
 
 // out[c] += sum_m src[m][c]
-__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* src, int sp, float* out, int64_t M, int C,
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* src, int sp, float* ws, int64_t M, int C,
                                                      int64_t ppb) {
     __shared__ float sred[256 * 8];
     const CGMap2 mp(C);
@@ -260,10 +271,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* src, 
             for (int j = 0; j < 8; ++j) s[j] += f[j];
         }
     }
+    float* r = ws + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * (C + 8);
     block_sum8b(s, sred, mp, tid);
     if (tid < mp.CG) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(out + c + j, s[j]);
+        for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s[j]);
     }
 }
 
@@ -367,16 +379,19 @@ extern "C" int aau_outconv_fwd(const aau_bf16* y, int y_pitch, const float* w, c
 }
 
 extern "C" int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlogits, const float* w, aau_bf16* dy,
-                               int dy_pitch, float* dw, float* db, int64_t M, int C, void* stream) {
-    AAU_REQUIRE(y && dlogits && w && dy && dw && M > 0, "aau_outconv_bwd: bad args");
+                               int dy_pitch, float* dw, float* db, float* ws, int64_t M, int C, void* stream) {
+    AAU_REQUIRE(y && dlogits && w && dy && dw && ws && M > 0, "aau_outconv_bwd: bad args");
     CHK_C("aau_outconv_bwd", C);
     AAU_REQUIRE(y_pitch % 8 == 0 && dy_pitch % 8 == 0, "aau_outconv_bwd: pitch");
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows(M, mp.PL, 16, 2048, &blocks, &ppb);
     ProfScope prof(2, 4.0 * M * C, (hipStream_t)stream);
+    hipMemsetAsync(ws, 0, (size_t)AAU_STAT_REPLICAS * (C + 8) * sizeof(float), (hipStream_t)stream);
     hipLaunchKernelGGL(outconv_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, y_pitch,
-                       dlogits, w, dy, dy_pitch, dw, db, M, C, ppb);
+                       dlogits, w, dy, dy_pitch, ws, M, C, ppb);
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, dw, C,
+                       db);
     return check_launch("aau_outconv_bwd");
 }
 
@@ -417,15 +432,18 @@ extern "C" int aau_gap_bwd(const aau_bf16* dpooled, aau_bf16* dx, int dx_pitch, 
     return check_launch("aau_gap_bwd");
 }
 
-extern "C" int aau_colsum(const aau_bf16* src, int src_pitch, float* out, int64_t M, int C, void* stream) {
-    AAU_REQUIRE(src && out && M > 0, "aau_colsum: bad args");
+extern "C" int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float* ws, int64_t M, int C, void* stream) {
+    AAU_REQUIRE(src && out && ws && M > 0, "aau_colsum: bad args");
     CHK_C("aau_colsum", C);
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows(M, mp.PL, 16, 1024, &blocks, &ppb);
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, src_pitch, out,
-                       M, C, ppb);
+    hipMemsetAsync(ws, 0, (size_t)AAU_STAT_REPLICAS * (C + 8) * sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, src_pitch, ws, M,
+                       C, ppb);
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, out, C,
+                       (float*)nullptr);
     return check_launch("aau_colsum");
 }
 

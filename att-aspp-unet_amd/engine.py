@@ -158,7 +158,7 @@ class ParamStore:
             n = e.R * e.T * e.Cpad
             off = dst
             dst += _ru(n, 8)
-            blk += (n + 255) // 256
+            blk += (n // 8 + 255) // 256
             return off, n
 
         mods = dict(model.named_modules())
@@ -264,7 +264,7 @@ class Plan:
         self.fwd.add("aau_bn_fold_eval", bn.gamma, bn.beta, bn.rm, bn.rv, w["scale"], w["shift"], bn.C, 1e-5)
 
     # ---- ConvBNReLU on MFMA: forward ----
-    def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0):
+    def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0, pool=None):
         """conv(cname) -> BN(bname) -> ReLU; returns the per-layer record used by the backward."""
         st = self.eng.store
         cv, bn = st.convs[cname], st.bns[bname]
@@ -278,8 +278,11 @@ class Plan:
             self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
             self._bn_finalize(bn, w, M)
             Mo = M * bcast_hw if bcast_hw else M
-            self.fwd.add("aau_bn_act", z, cv.O, ydst, yp, w["scale"], w["shift"], Mo, cv.O, 1, bcast_hw,
-                         self.drop_p if drop else 0.0, self.drop_seed)
+            if pool is not None:
+                self.fwd.add("aau_bn_act_pool", z, cv.O, ydst, yp, pool, cv.O, w["scale"], w["shift"], N, H, W, cv.O)
+            else:
+                self.fwd.add("aau_bn_act", z, cv.O, ydst, yp, w["scale"], w["shift"], Mo, cv.O, 1, bcast_hw,
+                             self.drop_p if drop else 0.0, self.drop_seed)
             rec["z"] = z
         else:
             self._bn_fold(bn, w)
@@ -292,6 +295,8 @@ class Plan:
             else:
                 d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, yp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f, relu=1)
                 self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, ydst, None, w["scale"], w["shift"], None)
+                if pool is not None:
+                    self.fwd.add("aau_maxpool2", ydst, yp, pool, cv.O, N, H, W, cv.O)
         return rec
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
@@ -350,18 +355,16 @@ class Plan:
             f.add("aau_conv1_fwd", self.x, cv0.w, z10, None, B, H, W, c)
             self._bn_fold(bn0, w0)
         f.add("aau_bn_act", z10, c, y10, c, w0["scale"], w0["shift"], Ms[0], c, 1, 0, 0.0, self.drop_seed)
-        r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, cat1, 2 * c)
+        r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, cat1, 2 * c, pool=pools[0])
         enc.append((r10, r11))
-        f.add("aau_maxpool2", cat1, 2 * c, pools[0], c, B, H, W, c)
         for lv in range(1, 4):
             h, w_ = Hs[lv], Ws[lv]
             ya = self.new(Ms[lv], Cs[lv])
             ra = self.cbr_fwd(f"d{lv + 1}.0.block.0", f"d{lv + 1}.0.block.1", pools[lv - 1], Cs[lv - 1], B, h, w_,
                               ya, Cs[lv])
             rb = self.cbr_fwd(f"d{lv + 1}.1.block.0", f"d{lv + 1}.1.block.1", ya, Cs[lv], B, h, w_, skips[lv],
-                              Cs[lv])
+                              Cs[lv], pool=pools[lv])
             enc.append((ra, rb))
-            f.add("aau_maxpool2", skips[lv], Cs[lv], pools[lv], Cs[lv], B, h, w_, Cs[lv])
 
         # ---------------- bridge: ASPP ----------------
         h5, w5, M5 = Hs[4], Ws[4], Ms[4]
@@ -438,7 +441,8 @@ class Plan:
         b = self.bwd
         mark = self._mark
         dy = self.new(Ms[0], c)
-        b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, Ms[0], c)
+        rep_ws = self.new(STAT_REPLICAS * (max(Cs) + 8), dtype=F32)   # replica scratch of the column reductions
+        b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, rep_ws, Ms[0], c)
         dskip = [None, self.new(Ms[1], Cs[1]), self.new(Ms[2], Cs[2]), self.new(Ms[3], Cs[3])]
         dcat1 = None
         for blk in reversed(dec):            # u1, u2, u3, u4
@@ -476,7 +480,7 @@ class Plan:
                                                       accumulate=1), dzx, wx.pk_d, dskip[lv], None, None, None, None)
             # ConvTranspose2d backward: bias, weight, input
             gsrc, gc = blk["g_in"], blk["g_c"]
-            b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, Mo, Co)
+            b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, rep_ws, Mo, Co)
             b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1),
                   dcat[:, Co:], gsrc, up.dw)
             dg_in = self.new(B * hi * wi, gc)

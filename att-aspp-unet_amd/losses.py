@@ -28,17 +28,17 @@ def sample_sums(l, t, edge=True):
     """Per-sample sums [B,8]: sum t, sum p, sum p*t, sum bce, sum |grad p - grad t|, sum pbin, sum pbin*t."""
     l, t = _check(l, t)
     B, _, H, W = l.shape
-    sums = torch.empty(B, 8, device=l.device)
+    sums = torch.empty(32, B, 8, device=l.device)
     out = torch.empty(4, device=l.device)
     ops.criterion(l, t, sums, out, None, B, H, W, False, 1.0, 1.0 if edge else 0.0)
-    return sums
+    return sums[0]
 
 
 class _CritFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, l, t, finetune, neg_bce_w, edge_w):
         B, _, H, W = l.shape
-        sums = torch.empty(B, 8, device=l.device)
+        sums = torch.empty(32, B, 8, device=l.device)
         out = torch.empty(4, device=l.device)
         dl = torch.empty_like(l)
         ops.criterion(l, t, sums, out, dl, B, H, W, finetune, neg_bce_w, edge_w)
@@ -127,7 +127,7 @@ def seg_metrics(l, t, thr=0.5):
     """-> device tensor [2]: (mean soft Dice = 1 - DiceLoss, mean hard IoU); no host sync."""
     l, t = _check(l, t)
     B, _, H, W = l.shape
-    sums = torch.empty(B, 8, device=l.device)
+    sums = torch.empty(32, B, 8, device=l.device)
     out = torch.empty(2, device=l.device)
     ops.seg_metrics(l, t, sums, out, B, H, W, thr)
     return out

@@ -86,6 +86,11 @@ def bn_act(z, zp, y, yp, scale, shift, M, Cc, relu=1, bcast_hw=0, drop_p=0.0, dr
                            drop_seed, _stream()), "aau_bn_act")
 
 
+def bn_act_pool(z, zp, y, yp, p, pp, scale, shift, N, H, W, Cc):
+    check(fn("aau_bn_act_pool")(_p(z), zp, _p(y), yp, _p(p), pp, _p(scale), _p(shift), N, H, W, Cc, _stream()),
+          "aau_bn_act_pool")
+
+
 def maxpool2(y, yp, p, pp, N, H, W, Cc):
     check(fn("aau_maxpool2")(_p(y), yp, _p(p), pp, N, H, W, Cc, _stream()), "aau_maxpool2")
 
@@ -147,13 +152,13 @@ def outconv_fwd(y, yp, w, b, logits, M, Cc):
     check(fn("aau_outconv_fwd")(_p(y), yp, _p(w), _p(b), _p(logits), M, Cc, _stream()), "aau_outconv_fwd")
 
 
-def outconv_bwd(y, yp, dlogits, w, dy, dyp, dw, db, M, Cc):
-    check(fn("aau_outconv_bwd")(_p(y), yp, _p(dlogits), _p(w), _p(dy), dyp, _p(dw), _p(db), M, Cc, _stream()),
-          "aau_outconv_bwd")
+def outconv_bwd(y, yp, dlogits, w, dy, dyp, dw, db, ws, M, Cc):
+    check(fn("aau_outconv_bwd")(_p(y), yp, _p(dlogits), _p(w), _p(dy), dyp, _p(dw), _p(db), _p(ws), M, Cc,
+                                _stream()), "aau_outconv_bwd")
 
 
-def colsum(src, sp, out, M, Cc):
-    check(fn("aau_colsum")(_p(src), sp, _p(out), M, Cc, _stream()), "aau_colsum")
+def colsum(src, sp, out, ws, M, Cc):
+    check(fn("aau_colsum")(_p(src), sp, _p(out), _p(ws), M, Cc, _stream()), "aau_colsum")
 
 
 def criterion(logits, targets, sums, loss_out, dlogits, B, H, W, finetune=False, neg_bce_w=0.05, edge_w=0.05,

@@ -165,8 +165,8 @@ class TrainStep:
         assert m.training, "TrainStep needs model.train()"
         plan = m._plan_for(x)
         B, _, H, W = x.shape
-        if self.sums is None or self.sums.shape[0] != B:
-            self.sums = torch.zeros(B, 8, device=x.device)
+        if self.sums is None or self.sums.shape[1] != B:
+            self.sums = torch.zeros(32, B, 8, device=x.device)
             self.loss = torch.zeros(4, device=x.device)
         logits = plan.run_forward(x)
         ops.criterion(logits, y, self.sums, self.loss, plan.dlogits, B, H, W, self.finetune, self.neg_w, self.edge_w)

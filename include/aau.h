@@ -105,7 +105,7 @@ int aau_conv1_wgrad(const float* x, const aau_bf16* dz, float* dw /*[C][9]*/,
 /* ---- weight packing (fp32 master -> bf16 GEMM operands), table driven ---------------- */
 typedef struct aau_pack_entry {
     int64_t src_off;        /* element offset into the flat fp32 parameter buffer        */
-    int64_t dst_off;        /* element offset into the packed bf16 buffer                */
+    int64_t dst_off;        /* element offset into the packed bf16 buffer (multiple of 8) */
     int32_t R;              /* rows of the packed matrix                                 */
     int32_t T;              /* taps                                                      */
     int32_t C;              /* channels per tap                                          */
@@ -114,7 +114,8 @@ typedef struct aau_pack_entry {
     int32_t t_flip;         /* 1: packed tap t reads source tap T-1-t                    */
     int32_t R2;             /* 0, or: row r = r1*R2 + r2 with strides (s_r, s_r2)        */
     int32_t s_r2;
-    int64_t blk_begin;      /* first thread block of this entry (prefix sum)             */
+    int64_t blk_begin;      /* first thread block of this entry: prefix sum of           */
+                            /* ceil(R*T*Cpad/8 / 256) (a thread packs 8 channels)        */
 } aau_pack_entry;
 int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_pack_entry* table_dev,
                      int n_entries, int64_t total_blocks, void* stream);
@@ -135,6 +136,9 @@ int aau_bn_fold_eval(const float* gamma, const float* beta, const float* running
 int aau_bn_act(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pitch, const float* scale,
                const float* shift, int64_t M, int C, int relu, int64_t bcast_hw,
                float drop_p, uint64_t drop_seed, void* stream);
+/* y = relu(z*scale+shift) and p = MaxPool2d(2)(y) in one pass (encoder stages, :115-118)   */
+int aau_bn_act_pool(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pitch, aau_bf16* p, int p_pitch,
+                    const float* scale, const float* shift, int N, int H, int W, int C, void* stream);
 /* MaxPool2d(2) (pipeline:115-118)                                                        */
 int aau_maxpool2(const aau_bf16* y, int y_pitch, aau_bf16* p, int p_pitch, int N, int H, int W,
                  int C, void* stream);
@@ -199,15 +203,18 @@ int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_bf16* zx,
 /* ---- out_conv: Conv2d(C, 1, 1) with bias (pipeline:122) -------------------------------- */
 int aau_outconv_fwd(const aau_bf16* y, int y_pitch, const float* w, const float* b,
                     float* logits, int64_t M, int C, void* stream);
+/* ws: fp32 [AAU_STAT_REPLICAS][C+8] workspace (zeroed by the call)                          */
 int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlogits, const float* w,
-                    aau_bf16* dy, int dy_pitch, float* dw, float* db, int64_t M, int C,
+                    aau_bf16* dy, int dy_pitch, float* dw, float* db, float* ws, int64_t M, int C,
                     void* stream);
-/* per-channel sum over pixels of a bf16 tensor into fp32 (ConvTranspose2d bias gradient)   */
-int aau_colsum(const aau_bf16* src, int src_pitch, float* out, int64_t M, int C, void* stream);
+/* out[c] += per-channel sum over pixels of a bf16 tensor (ConvTranspose2d bias gradient);   */
+/* ws as above                                                                              */
+int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float* ws, int64_t M, int C, void* stream);
 
 /* ---- criterion (pipeline:219-232 build_criterion with ComboLoss :187-189, DiceLoss        */
 /* :173-178, EdgeLoss :196-216) and metrics (:191-194 iou_score, :240 eval Dice) -------- */
-/* sums: fp32 [B][8] workspace (zeroed by the call); loss_out: fp32 [4] = total, dice,      */
+/* sums: fp32 [AAU_STAT_REPLICAS][B][8] workspace (zeroed by the call; [0] holds the per-   */
+/* sample sums afterwards); loss_out: fp32 [4] = total, dice,                               */
 /* bce, edge.  dlogits (optional, fp32 [B*H*W]) receives d(loss*loss_scale)/d(logits).       */
 int aau_criterion(const float* logits, const float* targets, float* sums, float* loss_out,
                   float* dlogits, int B, int H, int W, int finetune, float neg_bce_w,

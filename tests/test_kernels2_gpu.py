@@ -156,7 +156,7 @@ def test_gap_spatial_sum_colsum_broadcast(ops):
     ssum = zeros(N, C, dtype=torch.bfloat16)
     ops.spatial_sum(xd, C, ssum, ws, N, HW, C)
     cs = zeros(C)
-    ops.colsum(xd, C, cs, N * HW, C)
+    ops.colsum(xd, C, cs, zeros(ops.STAT_REPLICAS, C + 8), N * HW, C)
     torch.cuda.synchronize()
     assert rel_err(pooled.cpu(), x.mean(1)) < 6e-3
     assert rel_err(ssum.cpu(), x.sum(1)) < 6e-3
@@ -244,7 +244,7 @@ def test_outconv_forward_backward(ops):
     logits = zeros(M)
     ops.outconv_fwd(dev(bf(y)), C, dev(w), dev(b), logits, M, C)
     dy, dw, db = zeros(M, C, dtype=torch.bfloat16), zeros(C), zeros(1)
-    ops.outconv_bwd(dev(bf(y)), C, dev(dl), dev(w), dy, C, dw, db, M, C)
+    ops.outconv_bwd(dev(bf(y)), C, dev(dl), dev(w), dy, C, dw, db, zeros(ops.STAT_REPLICAS, C + 8), M, C)
     torch.cuda.synchronize()
     assert rel_err(logits.cpu(), y @ w + b) < 1e-5
     assert rel_err(dy.cpu(), dl[:, None] * w[None, :]) < 6e-3
@@ -258,14 +258,14 @@ def test_criterion_and_metrics_against_reference_golden(ops, golden):
         l, t = dev(torch.from_numpy(g[f"{tag}/logits"])), dev(torch.from_numpy(g[f"{tag}/targets"]))
         B, _, H, W = l.shape
         for stage in ("main", "finetune"):
-            sums, out, dl = zeros(B, 8), zeros(4), zeros(B, 1, H, W)
+            sums, out, dl = zeros(32, B, 8), zeros(4), zeros(B, 1, H, W)
             ops.criterion(l, t, sums, out, dl, B, H, W, finetune=(stage == "finetune"))
             torch.cuda.synchronize()
             ref_loss = float(g[f"{tag}/{stage}/loss"])
             assert abs(float(out[0].item()) - ref_loss) < 2e-5 * max(1, abs(ref_loss)), (tag, stage)
             ref_d = torch.from_numpy(g[f"{tag}/{stage}/dlogits"])
             assert float((dl.cpu() - ref_d).abs().max()) < 2e-4 * float(ref_d.abs().max()) + 1e-9, (tag, stage)
-        sums, m = zeros(B, 8), zeros(2)
+        sums, m = zeros(32, B, 8), zeros(2)
         ops.seg_metrics(l, t, sums, m, B, H, W, 0.5)
         torch.cuda.synchronize()
         assert abs(float(m[0].item()) - float(g[f"{tag}/dice_eval"])) < 1e-5
@@ -319,7 +319,7 @@ def test_pack_weights_table(ops):
         entries.append(e)
         tot = e.R * e.T * e.Cpad
         dst += tot
-        blk += (tot + 255) // 256
+        blk += (tot // 8 + 255) // 256
         return dst - tot, tot
 
     o1, n1 = add(src_off=0, R=O_, T=T, C=I_, Cpad=32, s_r=T * I_, s_t=I_, s_c=1, t_flip=0, R2=0, s_r2=0)
