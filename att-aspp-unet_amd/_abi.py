@@ -11,7 +11,7 @@ import re
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
-LIB_PATH = os.path.join(PKG, "lib", "libaau.so")
+LIB_PATH = os.environ.get("AAU_LIB") or os.path.join(PKG, "lib", "libaau.so")  # AAU_LIB: kernel-ablation builds
 HEADER = os.path.join(ROOT, "include", "aau.h")
 
 STAT_REPLICAS = 32

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libaau.so")
-SOURCES = ["runtime.hip", "igemm.hip", "wgrad.hip", "bn.hip", "pointwise.hip", "gate.hip", "loss.hip", "optim.hip"]
+SOURCES = ["runtime.hip", "igemm.hip", "conv3x3.hip", "wgrad.hip", "wgrad3x3.hip", "bn.hip", "pointwise.hip", "gate.hip", "loss.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wno-unused-result", "-Wno-unused-value"]
 
@@ -24,9 +24,12 @@ def _newer(src: str, dst: str) -> bool:
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") -> str:
+    """``defines`` / ``tag`` build an ablation variant ``lib/libaau_<tag>.so`` (see scripts/)."""
+    global LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(PKG, "build")
+    objdir = os.path.join(PKG, "build" + ("_" + tag if tag else ""))
+    lib_out = os.path.join(LIBDIR, f"libaau_{tag}.so") if tag else LIB
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     deps = [os.path.join(ROOT, "include", "aau.h"), os.path.join(CSRC, "common.h")]
@@ -39,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 
@@ -51,13 +54,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if rc != 0:
                     raise RuntimeError(f"hipcc failed on {src}:\n{out}")
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if force or jobs or not os.path.exists(lib_out):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_out, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}{r.stderr}")
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    tags = [a[6:] for a in sys.argv[1:] if a.startswith("--tag=")]
+    print(build(force="--force" in sys.argv, defines=defs, tag=tags[0] if tags else ""))

@@ -1,0 +1,338 @@
+// Halo-tiled 3x3 (stride 1, pad 1, dilation 1) convolution on MFMA for gfx950: forward and
+// data-gradient of every ConvBNReLU of the network (pipeline:63 via :113-121) -- 80 % of its FLOPs.
+//
+// The generic implicit-GEMM kernel (igemm.hip) re-gathers the activation tile for each of the
+// 9 taps, so its L2 -> LDS fill traffic is 9x the tile; at 128x96 tiles that fill rate, not
+// the MFMA, bounds it.  Here a workgroup owns a 16x16 spatial patch (256 output pixels) x BQ
+// output channels.  Per 32-channel chunk the 18x18 halo of the patch is staged ONCE
+// (buffer_load ... lds, zero fill of the image border by the descriptor range check) and all
+// 9 taps read their shifted 16-pixel rows out of it; only the small weight tile
+// [BQ][32] is streamed per (chunk, tap) step through a 3-slot ring.
+//
+// Pipeline: loads run 2 steps (weights) / 9 steps (next halo) ahead and stay in flight across
+// the per-step barrier: counted s_waitcnt vmcnt(N) + raw s_barrier, never vmcnt(0) in the loop.
+// Every wave issues the same number of LDS-DMA instructions per tile (the last one of a weight
+// tile is lane-masked) so the counts are wave-uniform constants.
+// 4 waves, each 4 patch rows x 16 px x BQ channels (24 / 12 accumulator tiles of
+// v_mfma_f32_16x16x32_bf16); 66 / 57 KiB LDS -> 2 workgroups per CU.
+#include "common.h"
+
+namespace aau {
+
+struct C3Args {
+    aau_conv_desc d;
+    const unsigned short* src;
+    const unsigned short* wpk;
+    unsigned short* dst;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    float* stats;
+    int nchunk;          // Cpad / 32
+    unsigned src_bytes, wpk_bytes;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ int swz32(int row, int lc) { return lc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
+
+// s_waitcnt takes an immediate: dispatch a wave-uniform runtime count to literal forms.
+// Waiting for a smaller count than necessary is always safe, so the default clamps down.
+__device__ __forceinline__ void wait_vm(int n) {
+#define AAU_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        AAU_W(0) AAU_W(1) AAU_W(2) AAU_W(3) AAU_W(4) AAU_W(5) AAU_W(6) AAU_W(7) AAU_W(8) AAU_W(9) AAU_W(10)
+        AAU_W(11) AAU_W(12) AAU_W(13) AAU_W(14) AAU_W(15) AAU_W(16)
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    }
+#undef AAU_W
+}
+
+template <int BQ>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
+    constexpr int BK = 32;
+    constexpr int HW_ = 18;                 // halo width / height
+    constexpr int HROWS = HW_ * HW_;        // 324 halo pixels
+    constexpr int HPAD = 384;               // rows staged (24 wave-instructions of 16 rows)
+    constexpr int NI = BQ / 16;             // channel tiles per wave
+    constexpr int MI = 4;                   // patch rows per wave
+    constexpr int WL = (BQ == 96) ? 2 : 1;  // weight-tile LDS-DMA instructions per wave
+    constexpr int HL = 6;                   // halo LDS-DMA instructions per wave
+    constexpr int NS = 3;                   // weight ring slots (deeper rings measured slower: not latency bound)
+    constexpr int PD = NS - 1;              // weight tiles are issued PD steps ahead
+    constexpr int HALO_E = HPAD * BK;       // elements
+    constexpr int WT_E = BQ * BK;
+    constexpr unsigned OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HALO_E + NS * WT_E];
+    auto sH = [&](int b) -> unsigned short* { return smem + b * HALO_E; };
+    auto sWt = [&](int slot) -> unsigned short* { return smem + 2 * HALO_E + slot * WT_E; };
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    // tile order: channel tile fastest, then patches; bijective XCD remap (see igemm.hip)
+    const int ntq = (d.Cout + BQ - 1) / BQ;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tq = bid % ntq;
+    int patch = bid / ntq;
+    const int px_t = patch % a.tiles_x;
+    patch /= a.tiles_x;
+    const int py_t = patch % a.tiles_y;
+    const int n = patch / a.tiles_y;
+    const int q0 = tq * BQ, y0 = py_t * 16, x0 = px_t * 16;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+
+    // ---- halo: this lane's (row, chunk slot) per instruction; byte offset of channel 0 or OOB ----
+    unsigned hoff[HL];
+    bool htail[HL];
+    const int tail_c0 = (a.nchunk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+        const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+        const int lc = swz32(hr, lane & 3);
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = hr < HROWS && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+        hoff[i] = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc * 8) * 2) : OOB;
+        htail[i] = tail_c0 + lc * 8 < d.Cin;
+    }
+    const bool has_tail = d.Cpad != d.Cin;
+    // ---- weights: rows of this wave's share of the [BQ][32] tile ----
+    constexpr int WROWS = BQ / 4;  // rows per wave: 24 or 12
+    unsigned woff[WL];
+#pragma unroll
+    for (int j = 0; j < WL; ++j) {
+        const int row = wave * WROWS + j * 16 + (lane >> 2);
+        const int lc = swz32(row, lane & 3);
+        const bool ok = (j * 16 + (lane >> 2)) < WROWS && (q0 + row) < d.Cout;
+        woff[j] = ok ? (unsigned)(((q0 + row) * 9 * d.Cpad + lc * 8) * 2) : OOB;
+    }
+    constexpr int WLAST = WROWS - (WL - 1) * 16;   // rows covered by the last instruction: 8 or 12
+    auto issue_halo = [&](int chunk) {
+        const bool last = has_tail && chunk == a.nchunk - 1;
+        unsigned short* base = sH(chunk & 1);
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+            const unsigned v = (last && !htail[i]) ? OOB : hoff[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + (i * 4 + wave) * 16 * BK), 16, (int)v,
+                                                     chunk * BK * 2, 0, 0);
+        }
+    };
+    auto issue_w = [&](int slot, int chunk, int tap) {
+        const int soff = (tap * d.Cpad + chunk * BK) * 2;
+        unsigned short* base = sWt(slot) + wave * WROWS * BK;
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            if (j < WL - 1) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(base + j * 16 * BK), 16, (int)woff[j], soff, 0, 0);
+            } else if (lane < WLAST * 4) {   // lane-masked tail: still ONE instruction per wave
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(base + j * 16 * BK), 16, (int)woff[j], soff, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fk = lane >> 4;
+    auto compute = [&](int hb, int slot, int tap) {
+        const int ty = tap / 3, tx = tap - ty * 3;
+        bf16x8 wf[NI], af[MI];
+        const unsigned short* wbase = sWt(slot);
+        const unsigned short* hbase = sH(hb);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = ni * 16 + fr;
+            wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
+            af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+#ifdef ABL_STAMP
+    unsigned long long tst[5];
+    tst[0] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- software pipeline over S = nchunk*9 (chunk, tap) steps ----
+    // issue order inside a step (after its barrier): [halo of the next chunk, at tap 0], then w(s+PD).
+    const int S = a.nchunk * 9;
+    issue_halo(0);
+    {
+        int c = 0, t = 0;
+        for (int k = 0; k < PD && k < S; ++k) {
+            issue_w(k, c, t);
+            if (++t == 9) { t = 0; ++c; }
+        }
+    }
+    int chunk = 0, tap = 0, slot = 0;
+    int ctap = PD % 9, cchunk = PD / 9, cslot = PD % NS;   // (chunk, tap, slot) of step s + PD
+    for (int s = 0; s < S; ++s) {
+        // outstanding loads younger than w(s): w(s+1 .. s+PD-1) that exist, plus the halo of the next
+        // chunk if it was issued during one of the last PD-1 steps (i.e. at this chunk's tap 0)
+        int nw = S - 1 - s;
+        if (nw > PD - 1) nw = PD - 1;
+        const bool halo_recent = tap >= 1 && tap <= PD - 1 && chunk + 1 < a.nchunk;
+#ifdef ABL_NOLOAD
+        wait_vm(0);
+#else
+        wait_vm(nw * WL + (halo_recent ? HL : 0));
+#endif
+#ifndef ABL_NOBARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+#ifdef ABL_STAMP
+        if (s == 0) tst[1] = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef ABL_NOLOAD
+        if (tap == 0 && chunk + 1 < a.nchunk) issue_halo(chunk + 1);
+        if (s + PD < S) issue_w(cslot, cchunk, ctap);
+#endif
+#ifdef ABL_NOLDS
+        compute(0, 0, 0);
+#else
+        compute(chunk & 1, slot, tap);
+#endif
+        if (++tap == 9) { tap = 0; ++chunk; }
+        if (++slot == NS) slot = 0;
+        if (++ctap == 9) { ctap = 0; ++cchunk; }
+        if (++cslot == NS) cslot = 0;
+    }
+
+#ifdef ABL_STAMP
+    tst[2] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- epilogue (same contract as igemm.hip) ----
+    const bool want_stats = a.stats != nullptr;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int y = y0 + wave * MI + mi, x = x0 + fr;
+        const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int q = q0 + ni * 16 + 4 * fk;
+            if (q >= d.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+            if (want_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[ni][r] += v[r]; s2[ni][r] += v[r] * v[r]; }
+            }
+            if (a.bias) {
+                const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (a.scale) {
+                const f32x4 sc = *(const f32x4*)(a.scale + q);
+                const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+            }
+            unsigned short* out = a.dst + pixel * d.dst_pitch + q;
+            if (d.accumulate) {
+                const u32x2 old = *(const u32x2*)out;
+                v[0] += __uint_as_float(old[0] << 16);
+                v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                v[2] += __uint_as_float(old[1] << 16);
+                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+            }
+            if (d.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            u32x2 pk;
+            pk[0] = pack2(v[0], v[1]);
+            pk[1] = pack2(v[2], v[3]);
+#ifdef ABL_NOSTORE
+            if (pk[0] == 0x12345678u && pk[1] == 0x9abcdef0u)
+#endif
+            *(u32x2*)out = pk;
+        }
+    }
+#ifdef ABL_NOSTATS
+    if (false) {
+#else
+    if (want_stats) {
+#endif
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x1 = s1[ni][r], x2 = s2[ni][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    x1 += __shfl_xor(x1, o, 64);
+                    x2 += __shfl_xor(x2, o, 64);
+                }
+                const int q = q0 + ni * 16 + 4 * fk + r;
+                if (fr == 0 && q < d.Cout) {
+                    atomicAdd(st + q, x1);
+                    atomicAdd(st + d.Cout + q, x2);
+                }
+            }
+        }
+    }
+#ifdef ABL_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tst[3] = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && a.shift != nullptr && a.scale == nullptr) {
+        unsigned long long* dbg = (unsigned long long*)a.shift + (size_t)blockIdx.x * 4;
+        dbg[0] = tst[0]; dbg[1] = tst[1]; dbg[2] = tst[2]; dbg[3] = tst[3];
+    }
+#endif
+}
+
+// true when the halo kernel applies to this descriptor
+bool conv3x3_applicable(const aau_conv_desc* d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->shuffle2x2 &&
+           d->H == d->Ho && d->W == d->Wo && d->H % 16 == 0 && d->W % 16 == 0 && d->Cpad % 32 == 0;
+}
+
+int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
+                   const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
+                   hipStream_t s) {
+    C3Args a;
+    a.d = *d;
+    a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
+    a.nchunk = d->Cpad / 32;
+    a.src_bytes = src_bytes;
+    a.wpk_bytes = wpk_bytes;
+    a.tiles_x = d->W / 16;
+    a.tiles_y = d->H / 16;
+    const bool narrow = d->Cout <= 48;
+    const int BQ = narrow ? 48 : 96;
+    const int64_t grid = (int64_t)((d->Cout + BQ - 1) / BQ) * a.tiles_x * a.tiles_y * d->N;
+    if (grid <= 0 || grid > 0x7fffffff) { set_error("conv3x3: grid out of range"); return AAU_E_INVALID; }
+    if (narrow) hipLaunchKernelGGL((conv3x3_kernel<48>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<96>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    return check_launch("aau_conv_igemm(3x3 halo)");
+}
+
+}  // namespace aau

@@ -339,6 +339,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 }
 
+// conv3x3.hip
+bool conv3x3_applicable(const aau_conv_desc* d);
+int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
+                   const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
+                   hipStream_t s);
+
 template <int BK, int BQ>
 static int launch(const IgemmArgs& a, hipStream_t s) {
     constexpr int BP = (BQ == 96) ? 128 : 256;
@@ -370,7 +376,9 @@ extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const
     AAU_REQUIRE(d->H < 32768 && d->W < 32768, "aau_conv_igemm: spatial dims must be < 32768");
     AAU_REQUIRE((int64_t)d->N * d->H * d->W < 0x7fffffff && (int64_t)d->N * d->Ho * d->Wo < 0x7fffffff,
                 "aau_conv_igemm: pixel count overflows int32");
+#ifndef ABL_STAMP
     AAU_REQUIRE((scale == nullptr) == (shift == nullptr), "aau_conv_igemm: scale and shift come together");
+#endif
     AAU_REQUIRE(!d->shuffle2x2 || (d->Cout % 32 == 0), "aau_conv_igemm: shuffle2x2 needs Cout %% 32 == 0");
     AAU_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)wpk & 15) == 0 && ((uintptr_t)dst & 7) == 0,
                 "aau_conv_igemm: pointers must be 16-byte (src, wpk) / 8-byte (dst) aligned");
@@ -389,6 +397,9 @@ extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const
     a.nchunk = d->Cpad / (bk64 ? 64 : 32);
     const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
     ProfScope prof(0, flops, (hipStream_t)stream);
+    if (conv3x3_applicable(d))
+        return conv3x3_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes,
+                              (hipStream_t)stream);
     const bool narrow = d->Cout <= 48;
     if (bk64) return narrow ? launch<64, 48>(a, (hipStream_t)stream) : launch<64, 96>(a, (hipStream_t)stream);
     return narrow ? launch<32, 48>(a, (hipStream_t)stream) : launch<32, 96>(a, (hipStream_t)stream);

@@ -224,6 +224,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// wgrad3x3.hip
+bool wgrad3x3_applicable(const aau_conv_desc* d);
+int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, hipStream_t s);
+
 template <int TQ, int TC>
 static int launch(WgradArgs& a, hipStream_t s) {
     constexpr int KWAVES = 4 / (TQ * TC);
@@ -268,6 +272,7 @@ extern "C" int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const
     a.linear = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo);
     const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
     ProfScope prof(1, flops, (hipStream_t)stream);
+    if (wgrad3x3_applicable(d)) return wgrad3x3_launch(d, src, dz, dw, (hipStream_t)stream);
     const bool q2 = d->Cout > 48, c2 = d->Cin > 48;
     if (q2 && c2) return launch<2, 2>(a, (hipStream_t)stream);
     if (q2) return launch<2, 1>(a, (hipStream_t)stream);

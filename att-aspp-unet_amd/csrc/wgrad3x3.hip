@@ -1,0 +1,224 @@
+// Weight gradient of the 3x3 (stride 1, pad 1, dilation 1) convolutions on MFMA, all 9 taps
+// per workgroup (gfx950).
+//
+//   dw[q][tap][c] += sum_m dz[m][q] * x[m + off(tap)][c]
+//
+// The generic kernel (wgrad.hip) gives each workgroup ONE tap, so per 128-pixel K-step it
+// stages 24 KB for 36 MFMAs (24 FLOP per staged byte: L2->LDS fill bound).  Here a workgroup
+// owns a 48(q) x 48(c) slice of the gradient for ALL taps: the GEMM is
+// [48 q] x [9 taps * 48 c = 432 columns] with K = pixels.  Per K-step (an 8 x 16 pixel patch)
+// it stages the dz tile (12 KB) and the patch's 10 x 18 halo of x (17 KB, once for all 9 taps)
+// for 324 MFMAs: 183 FLOP per staged byte.
+//
+// Both tiles stay [pixel][channel] in LDS as the LDS-DMA delivers them; the MFMA operands
+// (8 consecutive pixels of one channel per lane) come out of ds_read_b64_tr_b16.  The
+// k <-> pixel map of a 32-pixel sub-step is k = 8g + 4h + e <-> (patch row h, column 4g + e):
+// each transposed read covers 4 consecutive LDS rows at any tap shift and a half-wave covers
+// 8 consecutive 96-byte rows -- conflict free.
+// 4 waves split the 27 column tiles (tap, 16-channel group) 7/7/7/6; each keeps 3 x 7
+// accumulator tiles.  Two LDS stages (58 KB) -> 2 workgroups per CU.  Split-K over patch
+// ranges, fp32 atomics into the channels_last gradient [Cout][9][Cin].
+#include "common.h"
+
+namespace aau {
+
+struct W3Args {
+    aau_conv_desc d;
+    const unsigned short* src;   // x   [N][H][W] pitch src_pitch, Cin channels
+    const unsigned short* dz;    // dz  [N][H][W] pitch dst_pitch, Cout channels
+    float* dw;
+    unsigned src_bytes, dz_bytes;
+    int npatch;                  // N * (H/8) * (W/16)
+    int patches_per_block, nsplit;
+    int tiles_x, tiles_y;        // W/16, H/8
+};
+
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
+    constexpr int YB = 128 * 96;            // dz tile bytes: 128 px x 48 ch
+    constexpr int XROWS = 180;              // 10 x 18 halo pixels
+    constexpr int XB = 20 * 1024;           // staged bytes (20 wave-instructions; rows >= 180 are zero fill)
+    constexpr int NLY = 3, NLX = 5;         // LDS-DMA instructions per wave per K-step
+    constexpr unsigned OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
+    auto sY = [&](int b) -> unsigned char* { return smem + b * (YB + XB); };
+    auto sX = [&](int b) -> unsigned char* { return smem + b * (YB + XB) + YB; };
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    const int ntc = (d.Cin + 47) / 48;
+    int bid = blockIdx.x;
+    const int split = bid % a.nsplit;
+    bid /= a.nsplit;
+    const int tc = bid % ntc;
+    const int tq = bid / ntc;
+    const int q0 = tq * 48, c0 = tc * 48;
+    const int p_begin = split * a.patches_per_block;
+    const int p_end = min(a.npatch, p_begin + a.patches_per_block);
+    if (p_begin >= p_end) return;
+
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+
+    // ---- fixed staging roles: 16-B piece p = instr*256... (wave-major so that each wave-instruction is 1 KiB linear) ----
+    int yrel[NLY];     // element offset of (patch row, column, channel slot) relative to the patch origin, or -1
+#pragma unroll
+    for (int i = 0; i < NLY; ++i) {
+        const int p = (i * 4 + wave) * 64 + lane;            // 0 .. 767
+        const int px = p / 6, s = p - px * 6;
+        const int r = px >> 4, cx = px & 15;
+        yrel[i] = (q0 + s * 8 < d.Cout) ? (r * d.W + cx) * d.dst_pitch + q0 + s * 8 : -1;
+    }
+    int xhy[NLX], xhx[NLX], xch[NLX];
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+        const int p = (i * 4 + wave) * 64 + lane;            // 0 .. 1279
+        const int px = p / 6, s = p - px * 6;
+        const int hy = px / 18, hx = px - hy * 18;
+        xhy[i] = (px < XROWS && c0 + s * 8 < d.Cin) ? hy : -100000;
+        xhx[i] = hx;
+        xch[i] = c0 + s * 8;
+    }
+
+    auto stage = [&](int buf, int patch) {
+        const int pxi = patch % a.tiles_x;
+        const int t2 = patch / a.tiles_x;
+        const int pyi = t2 % a.tiles_y;
+        const int n = t2 / a.tiles_y;
+        const int y0 = pyi * 8, x0 = pxi * 16;
+        const int org = ((n * d.H + y0) * d.W + x0);          // pixel index of the patch origin (scalar)
+#pragma unroll
+        for (int i = 0; i < NLY; ++i) {
+            const unsigned v = yrel[i] >= 0 ? (unsigned)((org * d.dst_pitch + yrel[i]) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY(buf) + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NLX; ++i) {
+            const int y = y0 - 1 + xhy[i], x = x0 - 1 + xhx[i];
+            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + xch[i]) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX(buf) + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
+        }
+    };
+
+    // ---- this wave's column tiles: ct = 7*wave + n, n = 0..6 (tap = ct/3, channel group j = ct%3) ----
+    f32x4 acc[3][7];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int n = 0; n < 7; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int coff[7];    // byte offset inside the halo image of (tap shift, channel group) for column tile n
+    const int nct = (wave == 3) ? 6 : 7;
+#pragma unroll
+    for (int n = 0; n < 7; ++n) {
+        int ct = 7 * wave + n;
+        if (ct > 26) ct = 26;
+        const int tap = ct / 3, j = ct - tap * 3;
+        const int ty = tap / 3, tx = tap - ty * 3;
+        coff[n] = (ty * 18 + tx) * 96 + j * 32;
+    }
+
+    const int g16 = lane >> 4, li = lane & 15;
+    const int rq = li >> 2, cp = (li & 3) * 4;   // transposed read: lane supplies row rq, columns cp..cp+3
+    const int ybase = (4 * g16 + rq) * 96 + cp * 2;              // + (2*ss + h)*16*96 + i*32
+    const int xbase = (4 * g16 + rq) * 96 + cp * 2;              // + (2*ss + h)*18*96 + coff[n]
+    auto compute = [&](int buf) {
+        const unsigned char* by = sY(buf);
+        const unsigned char* bx = sX(buf);
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int o = ybase + (2 * ss) * 16 * 96 + i * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o + 16 * 96));
+                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int n = 0; n < 7; ++n) {
+                if (n < nct) {   // wave-uniform
+                    const int o = xbase + (2 * ss) * 18 * 96 + coff[n];
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bx + o));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bx + o + 18 * 96));
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    int patch = p_begin;
+    stage(0, patch);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const bool more = patch + 1 < p_end;
+        if (more) stage(buf ^ 1, patch + 1);
+        compute(buf);
+        if (!more) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+        ++patch;
+    }
+
+    // acc[i][n][r] = D[q = q0 + i*16 + 4*g16 + r][tap, c = c0 + j*16 + li]
+#pragma unroll
+    for (int n = 0; n < 7; ++n) {
+        if (n >= nct) continue;
+        const int ct = 7 * wave + n;
+        const int tap = ct / 3, j = ct - tap * 3;
+        const int c = c0 + j * 16 + li;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + i * 16 + 4 * g16 + r;
+                if (q < d.Cout && c < d.Cin) atomicAdd(a.dw + ((int64_t)q * 9 + tap) * d.Cin + c, acc[i][n][r]);
+            }
+    }
+}
+
+bool wgrad3x3_applicable(const aau_conv_desc* d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && d->H == d->Ho &&
+           d->W == d->Wo && d->H % 8 == 0 && d->W % 16 == 0;
+}
+
+int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, hipStream_t s) {
+    W3Args a;
+    a.d = *d;
+    a.src = src; a.dz = dz; a.dw = dw;
+    const int64_t npix = (int64_t)d->N * d->H * d->W;
+    const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin) * 2, zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
+    if (sb >= 0x7fffffff || zb >= 0x7fffffff) { set_error("aau_conv_wgrad: tensors must stay below 2 GiB"); return AAU_E_INVALID; }
+    a.src_bytes = (unsigned)sb;
+    a.dz_bytes = (unsigned)zb;
+    a.tiles_x = d->W / 16;
+    a.tiles_y = d->H / 8;
+    a.npatch = d->N * a.tiles_x * a.tiles_y;
+    const int64_t tiles = (int64_t)((d->Cout + 47) / 48) * ((d->Cin + 47) / 48);
+    // every workgroup ends with 83 KB of fp32 atomics (chip-wide ~1.3 TB/s): keep the grid near one
+    // resident wave of workgroups (2 per CU) so the atomic traffic stays well below the MFMA time
+    // and a multiple of the 512 resident slots (no ragged second round)
+    const double flops = 2.0 * npix * (double)d->Cout * d->Cin * 9.0;
+    const int64_t target = flops >= 1.5e11 ? 1024 : 512;
+    int64_t nsplit = (target + tiles / 2) / tiles;
+    const int64_t maxsplit = (a.npatch + 3) / 4;             // at least 4 K-steps per workgroup
+    if (nsplit > maxsplit) nsplit = maxsplit;
+    if (nsplit < 1) nsplit = 1;
+    a.patches_per_block = (int)((a.npatch + nsplit - 1) / nsplit);
+    a.nsplit = (int)((a.npatch + a.patches_per_block - 1) / a.patches_per_block);
+    const int64_t grid = tiles * a.nsplit;
+    if (grid > 0x7fffffff) { set_error("aau_conv_wgrad: grid too large"); return AAU_E_INVALID; }
+    hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+    return check_launch("aau_conv_wgrad(3x3)");
+}
+
+}  // namespace aau

@@ -52,6 +52,12 @@ CONV_CASES = [
     (1, 16, 16, 8, 16, 3, 1),
     (1, 32, 32, 128, 200, 3, 18),
     (3, 12, 20, 104, 56, 3, 2),
+    # halo-tiled 3x3 kernel (H, W multiples of 16): narrow / wide tiles, channel tails, many chunks
+    (2, 32, 48, 96, 96, 3, 1),
+    (1, 16, 32, 200, 104, 3, 1),
+    (2, 16, 16, 64, 48, 3, 1),
+    (1, 48, 16, 8, 24, 3, 1),
+    (1, 16, 16, 384, 192, 3, 1),
 ]
 
 
@@ -97,7 +103,32 @@ def test_igemm_epilogue_bias_affine_relu_accumulate_pitch(ops):
     assert float(got[..., :16].abs().max()) == 0 and float(got[..., 16 + Cout:].abs().max()) == 0  # neighbours untouched
 
 
-@pytest.mark.parametrize("case", [(2, 16, 16, 48, 48, 3, 1), (1, 32, 32, 64, 96, 3, 6), (2, 8, 8, 96, 192, 1, 1)])
+def test_halo3x3_epilogue_bias_affine_relu_accumulate_pitch(ops):
+    N, H, W, Cin, Cout = 2, 16, 32, 40, 56
+    g = torch.Generator().manual_seed(55)
+    xw = R.bf16_round(torch.randn(N, H, W, Cin + 8, generator=g))
+    x = xw[..., 8:]
+    w = R.bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5)
+    bias, scale, shift = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    prev = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    ref = torch.relu((R.conv_fwd(x, w) + bias) * scale + shift + prev)
+    cpad = ops.cpad_of(Cin)
+    wide = torch.zeros(N, H, W, Cout + 16, dtype=torch.bfloat16, device="cuda")
+    wide[..., 8:8 + Cout] = dev(prev.to(torch.bfloat16))
+    d = ops.conv_desc(N, H, W, Cin, Cin + 8, H, W, Cout, Cout + 16, 3, 3, 1, 1, 1, cpad, accumulate=1, relu=1)
+    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    ops.conv_igemm(d, dev(xw.to(torch.bfloat16))[..., 8:], dev(pack_fwd(w, cpad)), wide[..., 8:], bias=dev(bias),
+                   scale=dev(scale), shift=dev(shift), stats=stats)
+    torch.cuda.synchronize()
+    got = wide.cpu()
+    assert rel_err(got[..., 8:8 + Cout], ref) < 8e-3
+    assert float(got[..., :8].abs().max()) == 0 and float(got[..., 8 + Cout:].abs().max()) == 0
+    raw = R.conv_fwd(x, w).reshape(-1, Cout)
+    assert torch.allclose(stats.sum(0).cpu()[1], (raw ** 2).sum(0), rtol=2e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 48, 48, 3, 1), (1, 32, 32, 64, 96, 3, 6), (2, 8, 8, 96, 192, 1, 1),
+                                  (2, 32, 16, 96, 48, 3, 1), (1, 16, 48, 40, 136, 3, 1)])
 def test_igemm_dgrad(ops, case):
     N, H, W, Cin, Cout, k, dil = case
     g = torch.Generator().manual_seed(17)
@@ -148,6 +179,11 @@ WGRAD_CASES = [
     (2, 8, 8, 192, 96, 1, 1),
     (1, 16, 16, 8, 16, 3, 1),
     (3, 12, 20, 104, 56, 3, 2),
+    # all-taps 3x3 kernel (H % 8 == 0, W % 16 == 0)
+    (2, 32, 48, 96, 96, 3, 1),
+    (1, 16, 32, 200, 104, 3, 1),
+    (3, 8, 16, 48, 144, 3, 1),
+    (1, 64, 64, 24, 40, 3, 1),
 ]
 
 
