@@ -114,7 +114,12 @@ def main():
     args = Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05)
     torch.manual_seed(2025)
     model = A.AttentionASPPUNet(base_c=a.base_c).to(dev).train()
-    dp = A.DataParallel(model) if world > 1 else None
+    force_dp = os.environ.get("AAU_FORCE_DP") == "1"     # exercise the DP path with one rank (sanity runs)
+    if force_dp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dp = A.DataParallel(model) if (world > 1 or force_dp) else None
     opt = A.FusedAdamW(model, lr=3e-4, weight_decay=A.WEIGHT_DECAY, max_grad_norm=A.GRAD_CLIP)
     step = A.TrainStep(model, opt, args, dp)
     x, y = synth.make_frames(a.batch, a.size, seed=2025 + rank)     # weak scaling: 8 new frames per rank
@@ -130,7 +135,7 @@ def main():
     for i in range(a.warmup):
         loss = run(x, y)
     barrier()
-    if a.graph and world == 1:
+    if a.graph and world == 1 and dp is None:
         try:
             g = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()
@@ -205,7 +210,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
