@@ -43,6 +43,16 @@ __device__ __forceinline__ u32x4 pack8(const float f[8]) {
     return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15); every lane of the row ends with the total.
+// Four VALU ops with DPP modifiers (quad swaps, half-mirror, mirror) -- no LDS crossbar traffic.
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+    return x;
+}
+
 // counter-based uniform in [0,1) for dropout: keyed by (seed, element index)
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;

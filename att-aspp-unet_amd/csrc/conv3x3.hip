@@ -35,16 +35,19 @@ struct C3Args {
 
 __device__ __forceinline__ int swz32(int row, int lc) { return lc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
 
-// s_waitcnt takes an immediate: dispatch a wave-uniform runtime count to literal forms.
-// Waiting for a smaller count than necessary is always safe, so the default clamps down.
-__device__ __forceinline__ void wait_vm(int n) {
-#define AAU_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n) {
-        AAU_W(0) AAU_W(1) AAU_W(2) AAU_W(3) AAU_W(4) AAU_W(5) AAU_W(6) AAU_W(7) AAU_W(8) AAU_W(9) AAU_W(10)
-        AAU_W(11) AAU_W(12) AAU_W(13) AAU_W(14) AAU_W(15) AAU_W(16)
-        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    }
-#undef AAU_W
+// s_waitcnt takes an immediate; the pipeline below only ever needs these four counts per tile shape
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 8, "count");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
 template <int BQ>
@@ -147,32 +150,39 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fk = lane >> 4;
-    auto compute = [&](int hb, int slot, int tap) {
+    // halo (B operand) fragments of a step can be fetched one step early: the halo of the current chunk
+    // landed long ago, only the weight tile of a step needs that step's barrier.
+    bf16x8 af[MI];
+    auto load_halo_frags = [&](int hb, int tap) {
         const int ty = tap / 3, tx = tap - ty * 3;
-        bf16x8 wf[NI], af[MI];
-        const unsigned short* wbase = sWt(slot);
         const unsigned short* hbase = sH(hb);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int row = ni * 16 + fr;
-            wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
-        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
             af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
         }
+    };
+    auto compute = [&](int slot, int next_hb, int next_tap, bool prefetch) {
+        bf16x8 wf[NI];
+        const unsigned short* wbase = sWt(slot);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = ni * 16 + fr;
+            wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+        }
+        bf16x8 cur[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) cur[mi] = af[mi];
+#ifdef C3_PREFETCH
+        if (prefetch) load_halo_frags(next_hb, next_tap);
+#endif
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], cur[mi], acc[ni][mi], 0, 0, 0);
     };
 
-#ifdef ABL_STAMP
-    unsigned long long tst[5];
-    tst[0] = __builtin_amdgcn_s_memtime();
-#endif
     // ---- software pipeline over S = nchunk*9 (chunk, tap) steps ----
     // issue order inside a step (after its barrier): [halo of the next chunk, at tap 0], then w(s+PD).
     const int S = a.nchunk * 9;
@@ -192,26 +202,29 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
         int nw = S - 1 - s;
         if (nw > PD - 1) nw = PD - 1;
         const bool halo_recent = tap >= 1 && tap <= PD - 1 && chunk + 1 < a.nchunk;
-#ifdef ABL_NOLOAD
-        wait_vm(0);
-#else
-        wait_vm(nw * WL + (halo_recent ? HL : 0));
-#endif
-#ifndef ABL_NOBARRIER
+        static_assert(PD == 2, "the literal wait counts below assume a 2-step weight prefetch");
+        if (halo_recent) { if (nw) wait_vm<HL + WL>(); else wait_vm<HL>(); }
+        else             { if (nw) wait_vm<WL>(); else wait_vm<0>(); }
         __builtin_amdgcn_s_barrier();
-#endif
 #ifdef ABL_STAMP
         if (s == 0) tst[1] = __builtin_amdgcn_s_memtime();
 #endif
-#ifndef ABL_NOLOAD
         if (tap == 0 && chunk + 1 < a.nchunk) issue_halo(chunk + 1);
         if (s + PD < S) issue_w(cslot, cchunk, ctap);
-#endif
-#ifdef ABL_NOLDS
-        compute(0, 0, 0);
+#ifndef C3_PREFETCH
+        load_halo_frags(chunk & 1, tap);
 #else
-        compute(chunk & 1, slot, tap);
+        if (s == 0) load_halo_frags(0, 0);
 #endif
+        {
+            // the next step's halo fragments: same chunk (taps 1..8) or, at tap 8, the next chunk's buffer,
+            // whose LDS-DMA was waited for before THIS step's barrier only if it was issued >= 2 steps ago:
+            // it was issued at tap 0 of this chunk, 8 steps back -> landed and visible.
+            const bool pf = s + 1 < S;
+            const int ntap = tap == 8 ? 0 : tap + 1;
+            const int nhb = tap == 8 ? ((chunk + 1) & 1) : (chunk & 1);
+            compute(slot, nhb, ntap, pf);
+        }
         if (++tap == 9) { tap = 0; ++chunk; }
         if (++slot == NS) slot = 0;
         if (++ctap == 9) { ctap = 0; ++cchunk; }
@@ -275,28 +288,29 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
             *(u32x2*)out = pk;
         }
     }
-#ifdef ABL_NOSTATS
-    if (false) {
-#else
     if (want_stats) {
-#endif
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        // per-wave row sums (DPP), combined across the 4 waves in LDS (the tiles are dead now),
+        // then ONE global atomic per channel and workgroup
+        float* sst = (float*)smem;                      // [2][BQ]
+        __syncthreads();                                // every wave is done reading the LDS tiles
+        if (tid < 2 * BQ) sst[tid] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x1 = s1[ni][r], x2 = s2[ni][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    x1 += __shfl_xor(x1, o, 64);
-                    x2 += __shfl_xor(x2, o, 64);
-                }
-                const int q = q0 + ni * 16 + 4 * fk + r;
-                if (fr == 0 && q < d.Cout) {
-                    atomicAdd(st + q, x1);
-                    atomicAdd(st + d.Cout + q, x2);
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0) {
+                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
+                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
                 }
             }
+        }
+        __syncthreads();
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        if (tid < 2 * BQ) {
+            const int which = tid / BQ, ql = tid - which * BQ;
+            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
         }
     }
 #ifdef ABL_STAMP

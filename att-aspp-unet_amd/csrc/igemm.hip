@@ -318,23 +318,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 
     if (want_stats) {
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        // per-wave row sums (DPP), combined across the waves in LDS (the tiles are dead now),
+        // then ONE global atomic per channel and workgroup
+        float* sst = (float*)smem;                      // [2][BQ]
+        __syncthreads();                                // every wave is done reading the LDS tiles
+        if (tid < 2 * BQ) sst[tid] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x1 = s1[ni][r], x2 = s2[ni][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    x1 += __shfl_xor(x1, o, 64);
-                    x2 += __shfl_xor(x2, o, 64);
-                }
-                const int q = q0 + wq * 48 + ni * 16 + 4 * fk + r;
-                if (fr == 0 && q < d.Cout) {
-                    atomicAdd(st + q, x1);
-                    atomicAdd(st + d.Cout + q, x2);
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0) {
+                    atomicAdd(sst + wq * 48 + ni * 16 + 4 * fk + r, x1);
+                    atomicAdd(sst + BQ + wq * 48 + ni * 16 + 4 * fk + r, x2);
                 }
             }
+        }
+        __syncthreads();
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        if (tid < 2 * BQ) {
+            const int which = tid / BQ, ql = tid - which * BQ;
+            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
         }
     }
 }
