@@ -61,6 +61,30 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [(5, 256, 256, 48, 48), (4, 256, 272, 96, 48), (4, 272, 256, 48, 96), (5, 256, 256, 8, 56)])
+def test_resident_weight_3x3_path(ops, case):
+    """>= 1024 patches of 16x16 and a small weight matrix select the persistent resident-weight kernel."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
+    w = R.bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    ref = torch.relu(R.conv_fwd(x, w) + bias)
+    raw = R.conv_fwd(x, w).reshape(-1, Cout)
+    cpad = ops.cpad_of(Cin)
+    d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout + 8, 3, 3, 1, 1, 1, cpad, relu=1)
+    out = torch.zeros(N, H, W, Cout + 8, dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(pack_fwd(w, cpad)), out, bias=dev(bias), stats=stats)
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert rel_err(got[..., :Cout], ref) < 6e-3
+    assert float(got[..., Cout:].abs().max()) == 0
+    s = stats.sum(0).cpu()
+    assert float((s[0] - raw.sum(0)).abs().max()) < 2e-3 * float(raw.abs().sum(0).max())
+    assert torch.allclose(s[1], (raw ** 2).sum(0), rtol=2e-3)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_igemm_forward_and_stats(ops, case):
     N, H, W, Cin, Cout, k, dil = case
