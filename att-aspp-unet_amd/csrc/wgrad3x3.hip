@@ -18,6 +18,7 @@
 // 4 waves split the 27 column tiles (tap, 16-channel group) 7/7/7/6; each keeps 3 x 7
 // accumulator tiles.  Two LDS stages (58 KB) -> 2 workgroups per CU.  Split-K over patch
 // ranges, fp32 atomics into the channels_last gradient [Cout][9][Cin].
+#include <stdlib.h>
 #include "common.h"
 
 namespace aau {
@@ -33,11 +34,21 @@ struct W3Args {
     int tiles_x, tiles_y;        // W/16, H/8
 };
 
+// QT = 16-channel q tiles per workgroup (3: 48 channels, 6: 96 channels); PR = patch rows per K-step.
+// <3, 8> (default): 21 accumulator tiles per wave, 20 transposed reads per 21 MFMAs, 2 waves per SIMD;
+// <6, 4> (opt-in): 42 tiles per wave, half the LDS reads per FLOP, but 200 VGPRs -> 1 wave per SIMD.
+template <int QT, int PR>
 __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
-    constexpr int YB = 128 * 96;            // dz tile bytes: 128 px x 48 ch
-    constexpr int XROWS = 180;              // 10 x 18 halo pixels
-    constexpr int XB = 20 * 1024;           // staged bytes (20 wave-instructions; rows >= 180 are zero fill)
-    constexpr int NLY = 3, NLX = 5;         // LDS-DMA instructions per wave per K-step
+    constexpr int BQ = QT * 16;
+    constexpr int NPX = PR * 16;                          // pixels per K-step
+    constexpr int QS = BQ / 8;                            // 16-B slots per dz row
+    constexpr int YPITCH = BQ * 2;                        // 96 or 192 bytes
+    constexpr int YB = NPX * YPITCH;                      // dz tile bytes
+    constexpr int XROWS = (PR + 2) * 18;                  // halo pixels
+    constexpr int NLX = (XROWS * 6 + 255) / 256;          // LDS-DMA instructions per wave per K-step (x halo)
+    constexpr int XB = NLX * 4 * 1024;                    // staged bytes (rows >= XROWS are zero fill)
+    constexpr int NLY = NPX * QS / 256;                   // dz tile
+    static_assert(NPX * QS % 256 == 0, "dz tile / threads");
     constexpr unsigned OOB = 0x80000000u;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
@@ -55,7 +66,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     bid /= a.nsplit;
     const int tc = bid % ntc;
     const int tq = bid / ntc;
-    const int q0 = tq * 48, c0 = tc * 48;
+    const int q0 = tq * BQ, c0 = tc * 48;
     const int p_begin = split * a.patches_per_block;
     const int p_end = min(a.npatch, p_begin + a.patches_per_block);
     if (p_begin >= p_end) return;
@@ -67,15 +78,17 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     int yrel[NLY];     // element offset of (patch row, column, channel slot) relative to the patch origin, or -1
 #pragma unroll
     for (int i = 0; i < NLY; ++i) {
-        const int p = (i * 4 + wave) * 64 + lane;            // 0 .. 767
-        const int px = p / 6, s = p - px * 6;
+        const int p = (i * 4 + wave) * 64 + lane;
+        const int px = p / QS, s = p - px * QS;
         const int r = px >> 4, cx = px & 15;
-        yrel[i] = (q0 + s * 8 < d.Cout) ? (r * d.W + cx) * d.dst_pitch + q0 + s * 8 : -1;
+        // 192-byte rows: XOR the 32-B granule with bit 2 of the row (source side), see wgrad.hip
+        const int sl = (QT == 6) ? ((((s >> 1) ^ ((px >> 2) & 1)) << 1) | (s & 1)) : s;
+        yrel[i] = (q0 + sl * 8 < d.Cout) ? (r * d.W + cx) * d.dst_pitch + q0 + sl * 8 : -1;
     }
     int xhy[NLX], xhx[NLX], xch[NLX];
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
-        const int p = (i * 4 + wave) * 64 + lane;            // 0 .. 1279
+        const int p = (i * 4 + wave) * 64 + lane;
         const int px = p / 6, s = p - px * 6;
         const int hy = px / 18, hx = px - hy * 18;
         xhy[i] = (px < XROWS && c0 + s * 8 < d.Cin) ? hy : -100000;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
         const int t2 = patch / a.tiles_x;
         const int pyi = t2 % a.tiles_y;
         const int n = t2 / a.tiles_y;
-        const int y0 = pyi * 8, x0 = pxi * 16;
+        const int y0 = pyi * PR, x0 = pxi * 16;
         const int org = ((n * d.H + y0) * d.W + x0);          // pixel index of the patch origin (scalar)
 #pragma unroll
         for (int i = 0; i < NLY; ++i) {
@@ -105,9 +118,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     };
 
     // ---- this wave's column tiles: ct = 7*wave + n, n = 0..6 (tap = ct/3, channel group j = ct%3) ----
-    f32x4 acc[3][7];
+    f32x4 acc[QT][7];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < QT; ++i)
 #pragma unroll
         for (int n = 0; n < 7; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     int coff[7];    // byte offset inside the halo image of (tap shift, channel group) for column tile n
@@ -123,19 +136,27 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
 
     const int g16 = lane >> 4, li = lane & 15;
     const int rq = li >> 2, cp = (li & 3) * 4;   // transposed read: lane supplies row rq, columns cp..cp+3
-    const int ybase = (4 * g16 + rq) * 96 + cp * 2;              // + (2*ss + h)*16*96 + i*32
+    const int yrow = 4 * g16 + rq;                               // dz row inside a 16-pixel patch row
     const int xbase = (4 * g16 + rq) * 96 + cp * 2;              // + (2*ss + h)*18*96 + coff[n]
     auto compute = [&](int buf) {
         const unsigned char* by = sY(buf);
         const unsigned char* bx = sX(buf);
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-            bf16x8 af[3];
+        for (int ss = 0; ss < PR / 2; ++ss) {
+            bf16x8 af[QT];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int o = ybase + (2 * ss) * 16 * 96 + i * 32;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o + 16 * 96));
+            for (int i = 0; i < QT; ++i) {
+                const int r0 = (2 * ss) * 16 + yrow, r1 = r0 + 16;
+                int o0, o1;
+                if constexpr (QT == 3) {
+                    o0 = r0 * 96 + i * 32 + cp * 2;
+                    o1 = r1 * 96 + i * 32 + cp * 2;
+                } else {   // granule swizzle of the 192-byte rows
+                    o0 = r0 * 192 + ((i ^ ((r0 >> 2) & 1)) * 32) + cp * 2;
+                    o1 = r1 * 192 + ((i ^ ((r1 >> 2) & 1)) * 32) + cp * 2;
+                }
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o1));
                 af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bx + o + 18 * 96));
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < QT; ++i)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
                 }
             }
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
         const int tap = ct / 3, j = ct - tap * 3;
         const int c = c0 + j * 16 + li;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < QT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + i * 16 + 4 * g16 + r;
@@ -191,22 +212,15 @@ bool wgrad3x3_applicable(const aau_conv_desc* d) {
            d->W == d->Wo && d->H % 8 == 0 && d->W % 16 == 0;
 }
 
-int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, hipStream_t s) {
-    W3Args a;
-    a.d = *d;
-    a.src = src; a.dz = dz; a.dw = dw;
-    const int64_t npix = (int64_t)d->N * d->H * d->W;
-    const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin) * 2, zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
-    if (sb >= 0x7fffffff || zb >= 0x7fffffff) { set_error("aau_conv_wgrad: tensors must stay below 2 GiB"); return AAU_E_INVALID; }
-    a.src_bytes = (unsigned)sb;
-    a.dz_bytes = (unsigned)zb;
+template <int QT, int PR>
+static int launch_w3(W3Args& a, const aau_conv_desc* d, int64_t npix, hipStream_t s) {
+    constexpr int BQ = QT * 16;
     a.tiles_x = d->W / 16;
-    a.tiles_y = d->H / 8;
+    a.tiles_y = d->H / PR;
     a.npatch = d->N * a.tiles_x * a.tiles_y;
-    const int64_t tiles = (int64_t)((d->Cout + 47) / 48) * ((d->Cin + 47) / 48);
-    // every workgroup ends with 83 KB of fp32 atomics (chip-wide ~1.3 TB/s): keep the grid near one
-    // resident wave of workgroups (2 per CU) so the atomic traffic stays well below the MFMA time
-    // and a multiple of the 512 resident slots (no ragged second round)
+    const int64_t tiles = (int64_t)((d->Cout + BQ - 1) / BQ) * ((d->Cin + 47) / 48);
+    // every workgroup ends with BQ x 432 fp32 atomics (chip-wide ~1.3 TB/s): keep the grid near one or two
+    // resident rounds of workgroups (2 per CU) so the atomic traffic stays well below the MFMA time
     const double flops = 2.0 * npix * (double)d->Cout * d->Cin * 9.0;
     const int64_t target = flops >= 1.5e11 ? 1024 : 512;
     int64_t nsplit = (target + tiles / 2) / tiles;
@@ -217,8 +231,23 @@ int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16*
     a.nsplit = (int)((a.npatch + a.patches_per_block - 1) / a.patches_per_block);
     const int64_t grid = tiles * a.nsplit;
     if (grid > 0x7fffffff) { set_error("aau_conv_wgrad: grid too large"); return AAU_E_INVALID; }
-    hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return check_launch("aau_conv_wgrad(3x3)");
+}
+
+int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, hipStream_t s) {
+    W3Args a;
+    a.d = *d;
+    a.src = src; a.dz = dz; a.dw = dw;
+    const int64_t npix = (int64_t)d->N * d->H * d->W;
+    const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin) * 2, zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
+    if (sb >= 0x7fffffff || zb >= 0x7fffffff) { set_error("aau_conv_wgrad: tensors must stay below 2 GiB"); return AAU_E_INVALID; }
+    a.src_bytes = (unsigned)sb;
+    a.dz_bytes = (unsigned)zb;
+    // The 96-channel variant halves the LDS reads per FLOP but needs 200 VGPRs (1 wave per SIMD): measured
+    // 1.7-1.9x SLOWER than <3, 8> at 2 waves per SIMD on the same device, so it stays opt-in (experiments).
+    if (d->Cout > 48 && getenv("AAU_W3_WIDE")) return launch_w3<6, 4>(a, d, npix, s);
+    return launch_w3<3, 8>(a, d, npix, s);
 }
 
 }  // namespace aau
