@@ -43,12 +43,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     constexpr int NPX = PR * 16;                          // pixels per K-step
     constexpr int QS = BQ / 8;                            // 16-B slots per dz row
     constexpr int YPITCH = BQ * 2;                        // 96 or 192 bytes
-    constexpr int YB = NPX * YPITCH;                      // dz tile bytes
+    constexpr int NLY = (NPX * QS + 255) / 256;           // LDS-DMA instructions per wave per K-step (dz tile)
+    constexpr int YB = NLY * 4 * 1024;                    // staged bytes (pieces past the tile are zero fill)
     constexpr int XROWS = (PR + 2) * 18;                  // halo pixels
     constexpr int NLX = (XROWS * 6 + 255) / 256;          // LDS-DMA instructions per wave per K-step (x halo)
     constexpr int XB = NLX * 4 * 1024;                    // staged bytes (rows >= XROWS are zero fill)
-    constexpr int NLY = NPX * QS / 256;                   // dz tile
-    static_assert(NPX * QS % 256 == 0, "dz tile / threads");
     constexpr unsigned OOB = 0x80000000u;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
         const int r = px >> 4, cx = px & 15;
         // 192-byte rows: XOR the 32-B granule with bit 2 of the row (source side), see wgrad.hip
         const int sl = (QT == 6) ? ((((s >> 1) ^ ((px >> 2) & 1)) << 1) | (s & 1)) : s;
-        yrel[i] = (q0 + sl * 8 < d.Cout) ? (r * d.W + cx) * d.dst_pitch + q0 + sl * 8 : -1;
+        yrel[i] = (px < NPX && q0 + sl * 8 < d.Cout) ? (r * d.W + cx) * d.dst_pitch + q0 + sl * 8 : -1;
     }
     int xhy[NLX], xhx[NLX], xch[NLX];
 #pragma unroll
@@ -247,6 +246,7 @@ int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16*
     // The 96-channel variant halves the LDS reads per FLOP but needs 200 VGPRs (1 wave per SIMD): measured
     // 1.7-1.9x SLOWER than <3, 8> at 2 waves per SIMD on the same device, so it stays opt-in (experiments).
     if (d->Cout > 48 && getenv("AAU_W3_WIDE")) return launch_w3<6, 4>(a, d, npix, s);
+    if (getenv("AAU_W3_PR4")) return launch_w3<3, 4>(a, d, npix, s);   // experiment: 4 workgroups per CU
     return launch_w3<3, 8>(a, d, npix, s);
 }
 

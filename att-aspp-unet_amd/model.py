@@ -8,7 +8,9 @@ Class names, constructor signatures, child attribute names and therefore the 196
 order, so the same ``torch.manual_seed`` gives bit-identical initial weights and a
 reference checkpoint loads with ``strict=True``); their ATen ``forward`` is never
 called.  ``AttentionASPPUNet.forward`` replays the engine's recorded launch list; the
-backward pass is the engine's own, attached to autograd as a single node.
+backward pass is the engine's own, attached to autograd as a single node.  The block
+classes also run standalone (forward only, ``blocks.py``) with the reference's call
+signatures.
 
 There is no CPU / ATen fallback: calling the model on a non-HIP tensor raises.
 """
@@ -29,10 +31,29 @@ def _conv_bn(in_c, out_c, k, dilation=1, relu=True):
     return nn.Sequential(*layers)
 
 
-def _no_standalone(self, *a, **k):
-    raise _abi.AauError(
-        f"{type(self).__name__} is a parameter container of the HIP engine; run it through "
-        "AttentionASPPUNet (or att_aspp_unet_amd.blocks for single-block execution)")
+@torch.no_grad()
+def _fwd_cbr(self, x):
+    """Standalone forward (NCHW fp32 in / out, no autograd); see blocks.py."""
+    from . import blocks
+    return blocks.convbnrelu_forward(self, x)
+
+
+@torch.no_grad()
+def _fwd_aspp(self, x):
+    from . import blocks
+    return blocks.aspp_forward(self, x)
+
+
+@torch.no_grad()
+def _fwd_gate(self, g, x):
+    from . import blocks
+    return blocks.gate_forward(self, g, x)
+
+
+@torch.no_grad()
+def _fwd_up(self, g, x):
+    from . import blocks
+    return blocks.upblock_forward(self, g, x)
 
 
 class ConvBNReLU(nn.Module):
@@ -42,7 +63,7 @@ class ConvBNReLU(nn.Module):
         super().__init__()
         self.block = _conv_bn(in_c, out_c, k)
 
-    forward = _no_standalone
+    forward = _fwd_cbr
 
 
 class ASPP(nn.Module):
@@ -56,7 +77,7 @@ class ASPP(nn.Module):
         self.project = nn.Sequential(nn.Conv2d(out_c * (len(rates) + 2), out_c, 1, bias=False),
                                      nn.BatchNorm2d(out_c), nn.ReLU(True), nn.Dropout(0.1))
 
-    forward = _no_standalone
+    forward = _fwd_aspp
 
 
 class AttentionGate(nn.Module):
@@ -69,7 +90,7 @@ class AttentionGate(nn.Module):
         self.psi = nn.Sequential(nn.Conv2d(Fint, 1, 1, bias=False), nn.BatchNorm2d(1), nn.Sigmoid())
         self.relu = nn.ReLU(True)
 
-    forward = _no_standalone
+    forward = _fwd_gate
 
 
 class DummyAttention(nn.Module):
@@ -88,7 +109,7 @@ class UpBlock(nn.Module):
         self.att = AttentionGate(out_c, out_c, out_c // 2) if use_att else DummyAttention()
         self.conv = nn.Sequential(ConvBNReLU(in_c, out_c), ConvBNReLU(out_c, out_c))
 
-    forward = _no_standalone
+    forward = _fwd_up
 
 
 class _NetFn(torch.autograd.Function):
