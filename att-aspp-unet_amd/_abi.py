@@ -81,6 +81,7 @@ _SIGS = {
     "aau_nhwc_to_nchw": [P, I, P, I, I, I, I, P],
     "aau_hflip_f32": [P, P, I, I, I, P],
     "aau_tta_merge": [P, P, P, I, I, I, P],
+    "aau_window_blend": [P, P, I, I, I, I, I, I, F, P],
 }
 
 _lib = None

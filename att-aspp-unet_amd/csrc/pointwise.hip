@@ -321,6 +321,31 @@ __global__ void tta_merge_kernel(const float* l, const float* lf, float* prob, i
     }
 }
 
+// Gaussian-weighted blend of overlapping window logits into the full frame:
+// out[y][x] = sum_w g(y-wy, x-wx) * l_w[y-wy][x-wx] / sum_w g(...), windows on a regular grid (stride sy, sx)
+__global__ void window_blend_kernel(const float* wl, float* out, int H, int W, int win, int stride, int ny, int nx,
+                                    float inv_two_sigma2) {
+    const int64_t total = (int64_t)H * W;
+    const float c = 0.5f * (float)(win - 1);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        float acc = 0.f, wsum = 0.f;
+        for (int iy = 0; iy < ny; ++iy) {
+            const int ly = y - iy * stride;
+            if (ly < 0 || ly >= win) continue;
+            for (int ix = 0; ix < nx; ++ix) {
+                const int lx = x - ix * stride;
+                if (lx < 0 || lx >= win) continue;
+                const float dy = (float)ly - c, dx = (float)lx - c;
+                const float g = expf(-(dy * dy + dx * dx) * inv_two_sigma2);
+                acc += g * wl[((int64_t)(iy * nx + ix) * win + ly) * win + lx];
+                wsum += g;
+            }
+        }
+        out[i] = wsum > 0.f ? acc / wsum : 0.f;
+    }
+}
+
 static inline int grid1d(int64_t n, int cap = 4096) {
     int64_t g = (n + 255) / 256;
     if (g < 1) g = 1;
@@ -482,4 +507,14 @@ extern "C" int aau_tta_merge(const float* l, const float* l_flipped, float* prob
     hipLaunchKernelGGL(tta_merge_kernel, dim3(grid1d((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, l,
                        l_flipped, prob, (int64_t)N * H, W);
     return check_launch("aau_tta_merge");
+}
+
+extern "C" int aau_window_blend(const float* win_logits, float* out, int H, int W, int win, int stride, int ny, int nx,
+                                float sigma, void* stream) {
+    AAU_REQUIRE(win_logits && out && H > 0 && W > 0 && win > 0 && stride > 0 && ny > 0 && nx > 0 && sigma > 0.f,
+                "aau_window_blend: bad args");
+    AAU_REQUIRE((ny - 1) * stride + win >= H && (nx - 1) * stride + win >= W, "aau_window_blend: windows do not cover the frame");
+    hipLaunchKernelGGL(window_blend_kernel, dim3(grid1d((int64_t)H * W)), dim3(256), 0, (hipStream_t)stream, win_logits,
+                       out, H, W, win, stride, ny, nx, 1.0f / (2.f * sigma * sigma));
+    return check_launch("aau_window_blend");
 }

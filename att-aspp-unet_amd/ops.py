@@ -204,3 +204,8 @@ def hflip_f32(src, dst, N, H, W):
 
 def tta_merge(l, lf, prob, N, H, W):
     check(fn("aau_tta_merge")(_p(l), _p(lf), _p(prob), N, H, W, _stream()), "aau_tta_merge")
+
+
+def window_blend(win_logits, out, H, W, win, stride, ny, nx, sigma):
+    check(fn("aau_window_blend")(_p(win_logits), _p(out), H, W, win, stride, ny, nx, sigma, _stream()),
+          "aau_window_blend")

@@ -75,6 +75,53 @@ def predict_prob_tta(model, x):
     return prob[0, 0].cpu().numpy()
 
 
+class GraphedForward:
+    """Eval-mode forward of a fixed input shape captured once as a hipGraph and replayed (inference is
+    launch-latency bound at batch 1; the recorded plan has no host synchronisation, so it captures as is)."""
+
+    def __init__(self, model, shape, device="cuda"):
+        assert not model.training, "GraphedForward captures the eval plan"
+        self.model = model
+        self.x = torch.zeros(*shape, device=device)
+        with torch.no_grad():
+            for _ in range(2):
+                model(self.x)                      # builds the plan / warms the allocator outside of capture
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s), torch.cuda.graph(self.graph, stream=s):
+                self.out = model(self.x)
+            torch.cuda.current_stream().wait_stream(s)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+@torch.inference_mode()
+def predict_sliding_window(model, x, window=512, stride=256, sigma_frac=0.125, forward=None):
+    """Build-side extension (BASELINE config 5): tile a [1,1,H,W] frame into ``window`` x ``window`` crops on a
+    ``stride`` grid, run them as ONE batch through the network and blend the logits with a Gaussian weight
+    (the scheme nnU-Net uses for the reference's baseline, model.py:41-49).  Returns logits [1,1,H,W].
+    ``forward`` may be a GraphedForward for the batch shape."""
+    assert x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 1
+    H, W = x.shape[2:]
+    assert H >= window and W >= window and (H - window) % stride == 0 and (W - window) % stride == 0, \
+        "frame must be covered exactly by the window grid"
+    ny, nx = (H - window) // stride + 1, (W - window) // stride + 1
+    crops = torch.empty(ny * nx, 1, window, window, device=x.device)
+    for iy in range(ny):
+        for ix in range(nx):
+            crops[iy * nx + ix, 0] = x[0, 0, iy * stride:iy * stride + window, ix * stride:ix * stride + window]
+    logits = (forward or model)(crops).contiguous()
+    out = torch.empty(1, 1, H, W, device=x.device)
+    ops.window_blend(logits, out, H, W, window, stride, ny, nx, sigma_frac * window)
+    return out
+
+
 def lr_at_epoch(ep, epochs, lr, stage="main"):
     """Closed form of pipeline:303-306 (LinearLR 0.2->1 for max(1, 5%) epochs, then cosine)."""
     warm = 0 if stage == "finetune" else max(1, int(0.05 * epochs))

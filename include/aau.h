@@ -243,6 +243,12 @@ int aau_nhwc_to_nchw(const aau_bf16* src, int src_pitch, float* dst, int N, int 
 int aau_hflip_f32(const float* src, float* dst, int N, int H, int W, void* stream);
 int aau_tta_merge(const float* l, const float* l_flipped, float* prob, int N, int H, int W, void* stream);
 
+/* Sliding-window inference (build-side extension, BASELINE config 5; the reference's Att-ASPP   */
+/* path has no tiling): Gaussian-weighted blend of ny*nx window logit maps            */
+/* [ny*nx][win][win] (window (iy,ix) at offset (iy*stride, ix*stride)) into out [H][W].           */
+int aau_window_blend(const float* win_logits, float* out, int H, int W, int win, int stride, int ny, int nx,
+                     float sigma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
