@@ -79,21 +79,25 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
     shift[c] = beta[c] - rmean[c] * sc;
 }
 
-// y = relu?(z*scale+shift) (* dropout), one 16-B vector per thread, grid-stride
+// y = relu?(z*scale+shift) (* dropout).  A thread owns one 8-channel group (scale / shift live in 16
+// registers) and walks over pixels; consecutive threads cover consecutive 16-B vectors of a pixel row.
 __global__ __launch_bounds__(256) void bn_act_kernel(const unsigned short* z, int zp, unsigned short* y, int yp,
                                                      const float* scale, const float* shift, int64_t M, int C,
-                                                     int relu, int64_t bhw, float drop_p, uint64_t seed) {
-    const int CG = C >> 3;
-    const int64_t total = M * CG;
+                                                     int relu, int64_t bhw, float drop_p, uint64_t seed,
+                                                     int64_t ppb) {
+    const CGMap mp(C);
+    const int tid = threadIdx.x;
+    if (tid >= mp.T) return;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float sc[8], sh[8];
+    ldf8(scale + c, sc);
+    ldf8(shift + c, sh);
     const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
-        const int64_t m = v / CG;
-        const int c = (int)(v - m * CG) * 8;
+    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
         const int64_t ms = bhw > 0 ? m / bhw : m;
-        float f[8], sc[8], sh[8];
+        float f[8];
         unpack8(ld16(z + ms * zp + c), f);
-        ldf8(scale + c, sc);
-        ldf8(shift + c, sh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float t = f[j] * sc[j] + sh[j];
@@ -128,24 +132,29 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const unsigned short* y, 
     }
 }
 
-// y = relu(z*scale+shift) and p = maxpool2x2(y) in one pass: one thread per 2x2 window and channel group
+// y = relu(z*scale+shift) and p = maxpool2x2(y) in one pass: a thread owns a channel group (constants in
+// registers) and walks over 2x2 windows
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const unsigned short* z, int zp, unsigned short* y, int yp,
                                                           unsigned short* p, int pp, const float* scale,
-                                                          const float* shift, int N, int H, int W, int C) {
-    const int CG = C >> 3, Ho = H >> 1, Wo = W >> 1;
-    const int64_t total = (int64_t)N * Ho * Wo * CG;
-    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
-        const int64_t mo = v / CG;
-        const int c = (int)(v - mo * CG) * 8;
+                                                          const float* shift, int N, int H, int W, int C, int64_t ipb) {
+    const CGMap mp(C);
+    const int tid = threadIdx.x;
+    if (tid >= mp.T) return;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t total = (int64_t)N * Ho * Wo;
+    float sc[8], sh[8];
+    ldf8(scale + c, sc);
+    ldf8(shift + c, sh);
+    const int64_t i0 = (int64_t)blockIdx.x * ipb, i1 = min(total, i0 + ipb);
+    for (int64_t mo = i0 + pl; mo < i1; mo += mp.PL) {
         const int xo = (int)(mo % Wo);
         const int64_t t = mo / Wo;
         const int yo = (int)(t % Ho);
         const int n = (int)(t / Ho);
         const int64_t p00 = ((int64_t)n * H + 2 * yo) * W + 2 * xo;
         const int64_t pix[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
-        float sc[8], sh[8], best[8];
-        ldf8(scale + c, sc);
-        ldf8(shift + c, sh);
+        float best[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float f[8];
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                     s2[j] += gv * zh;
                     g[j] = gv;
                 }
-                st16(dz + it * dzp + c, pack8(g));
+                if (dz) st16(dz + it * dzp + c, pack8(g));   // dz == null: the apply pass recomputes the mask from dy
             }
         }
     }
@@ -263,44 +272,77 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 }
 
 // ---- backward pass 2: dz = gamma*invstd*(g - mean(g) - zhat*mean(g*zhat)) in place ----
+// dy == null: the masked gradient g is read from dz (written by the reduce pass, pooled layers);
+// dy != null: g = relu'(z*scale+shift) * dropout(dy) is recomputed here, saving one tensor write + read.
+// A thread owns one channel group: its seven per-channel constants live in registers.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* z, int zp, unsigned short* dz, int dzp,
                                                            const float* gamma, const float* mean, const float* invstd,
                                                            const float* red, float* dgamma, float* dbeta, int64_t M,
-                                                           int C) {
-    extern __shared__ float sm[];  // [3][C]: k0 = gamma*invstd, k1 = mean(g), k2 = mean(g*zhat)
-    float* k0 = sm;
-    float* k1 = sm + C;
-    float* k2 = sm + 2 * C;
-    for (int c = threadIdx.x; c < C; c += 256) {
+                                                           int C, const unsigned short* dy, int dyp, const float* scale,
+                                                           const float* shift, int relu, float drop_p, uint64_t seed,
+                                                           int64_t ppb) {
+    extern __shared__ float sm[];   // [2][C] replica sums, computed once per workgroup
+    for (int cc = threadIdx.x; cc < C; cc += 256) {
         float a = 0.f, b = 0.f;
         for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
-            a += red[(size_t)r * 2 * C + c];
-            b += red[(size_t)r * 2 * C + C + c];
+            a += red[(size_t)r * 2 * C + cc];
+            b += red[(size_t)r * 2 * C + C + cc];
         }
-        k0[c] = gamma[c] * invstd[c];
-        k1[c] = a / (float)M;
-        k2[c] = b / (float)M;
+        sm[cc] = a;
+        sm[C + cc] = b;
         if (blockIdx.x == 0) {
-            if (dbeta) dbeta[c] += a;
-            if (dgamma) dgamma[c] += b;
+            if (dbeta) dbeta[cc] += a;
+            if (dgamma) dgamma[cc] += b;
         }
     }
     __syncthreads();
-    const int CG = C >> 3;
-    const int64_t total = M * CG;
-    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
-        const int64_t m = v / CG;
-        const int c = (int)(v - m * CG) * 8;
+    const CGMap mp(C);
+    const int tid = threadIdx.x;
+    if (tid >= mp.T) return;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float k0[8], k1[8], k2[8], mu[8], is[8], sc[8], sh[8];
+    ldf8(mean + c, mu);
+    ldf8(invstd + c, is);
+    if (dy) { ldf8(scale + c, sc); ldf8(shift + c, sh); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        k0[j] = gamma[c + j] * is[j];
+        k1[j] = sm[c + j] / (float)M;
+        k2[j] = sm[C + c + j] / (float)M;
+    }
+    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
         float zz[8], g[8];
         unpack8(ld16(z + m * zp + c), zz);
-        unpack8(ld16(dz + m * dzp + c), g);
+        if (dy) {
+            unpack8(ld16(dy + m * dyp + c), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float gv = g[j];
+                if (drop_p > 0.f) gv = hash_uniform(seed, (uint64_t)(m * C + c + j)) >= drop_p ? gv * keep_scale : 0.f;
+                if (relu && !(zz[j] * sc[j] + sh[j] > 0.f)) gv = 0.f;
+                g[j] = bf2f(f2bf(gv));   // same rounding as the stored form
+            }
+        } else {
+            unpack8(ld16(dz + m * dzp + c), g);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float zh = (zz[j] - mean[c + j]) * invstd[c + j];
-            g[j] = k0[c + j] * (g[j] - k1[c + j] - zh * k2[c + j]);
+            const float zh = (zz[j] - mu[j]) * is[j];
+            g[j] = k0[j] * (g[j] - k1[j] - zh * k2[j]);
         }
         st16(dz + m * dzp + c, pack8(g));
     }
+}
+
+// rows per block so that the grid is ~8 workgroups per CU and every thread gets a few iterations
+static inline void rows_split(int64_t M, int PL, int64_t* blocks, int64_t* ppb) {
+    int64_t b = (M + (int64_t)PL * 4 - 1) / ((int64_t)PL * 4);
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    *ppb = (M + b - 1) / b;
+    *blocks = (M + *ppb - 1) / *ppb;
 }
 
 static inline int grid_for(int64_t total_threads, int cap = 256 * 8) {
@@ -347,8 +389,10 @@ extern "C" int aau_bn_act(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pit
     AAU_REQUIRE(z_pitch % 8 == 0 && y_pitch % 8 == 0, "aau_bn_act: pitches must be multiples of 8");
     AAU_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "aau_bn_act: drop_p=%f", drop_p);
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, z, z_pitch, y,
-                       y_pitch, scale, shift, M, C, relu, bcast_hw, drop_p, drop_seed);
+    int64_t blocks, ppb;
+    rows_split(M, CGMap(C).PL, &blocks, &ppb);
+    hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, z_pitch, y,
+                       y_pitch, scale, shift, M, C, relu, bcast_hw, drop_p, drop_seed, ppb);
     return check_launch("aau_bn_act");
 }
 
@@ -359,8 +403,10 @@ extern "C" int aau_bn_act_pool(const aau_bf16* z, int z_pitch, aau_bf16* y, int 
     CHK_C("aau_bn_act_pool", C);
     AAU_REQUIRE(z_pitch % 8 == 0 && y_pitch % 8 == 0 && p_pitch % 8 == 0, "aau_bn_act_pool: pitches must be multiples of 8");
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_act_pool_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8), 256 * 16)), dim3(256), 0,
-                       (hipStream_t)stream, z, z_pitch, y, y_pitch, p, p_pitch, scale, shift, N, H, W, C);
+    int64_t blocks, ipb;
+    rows_split((int64_t)N * (H / 2) * (W / 2), CGMap(C).PL, &blocks, &ipb);
+    hipLaunchKernelGGL(bn_act_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, z_pitch, y,
+                       y_pitch, p, p_pitch, scale, shift, N, H, W, C, ipb);
     return check_launch("aau_bn_act_pool");
 }
 
@@ -381,7 +427,8 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
                                  const float* scale, const float* shift, const float* save_mean,
                                  const float* save_invstd, float* red, int N, int H, int W, int C, int relu,
                                  float drop_p, uint64_t drop_seed, void* stream) {
-    AAU_REQUIRE(z && dz && scale && shift && save_mean && save_invstd && red, "aau_bn_bwd_reduce: null pointer");
+    AAU_REQUIRE(z && scale && shift && save_mean && save_invstd && red, "aau_bn_bwd_reduce: null pointer");
+    AAU_REQUIRE(dz || !dpool, "aau_bn_bwd_reduce: the pooled form must store the masked gradient (dz != NULL)");
     AAU_REQUIRE(dy || dpool, "aau_bn_bwd_reduce: needs at least one gradient source");
     CHK_C("aau_bn_bwd_reduce", C);
     AAU_REQUIRE(z_pitch % 8 == 0 && dz_pitch % 8 == 0 && dy_pitch % 8 == 0 && dpool_pitch % 8 == 0,
@@ -414,13 +461,17 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
 
 extern "C" int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch, const float* gamma,
                                 const float* save_mean, const float* save_invstd, const float* red, float* dgamma,
-                                float* dbeta, int64_t M, int C, void* stream) {
+                                float* dbeta, int64_t M, int C, const aau_bf16* dy, int dy_pitch, const float* scale,
+                                const float* shift, int relu, float drop_p, uint64_t drop_seed, void* stream) {
     AAU_REQUIRE(z && dz && gamma && save_mean && save_invstd && red && M > 0, "aau_bn_bwd_apply: bad args");
+    AAU_REQUIRE(!dy || (scale && shift && dy_pitch % 8 == 0), "aau_bn_bwd_apply: dy needs scale/shift and an aligned pitch");
     CHK_C("aau_bn_bwd_apply", C);
     AAU_REQUIRE(z_pitch % 8 == 0 && dz_pitch % 8 == 0, "aau_bn_bwd_apply: pitches must be multiples of 8");
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 8))), dim3(256), 3 * C * sizeof(float),
-                       (hipStream_t)stream, z, z_pitch, dz, dz_pitch, gamma, save_mean, save_invstd, red, dgamma,
-                       dbeta, M, C);
+    int64_t blocks, ppb;
+    rows_split(M, CGMap(C).PL, &blocks, &ppb);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, z, z_pitch, dz,
+                       dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, M, C, dy, dy_pitch, scale, shift,
+                       relu, drop_p, drop_seed, ppb);
     return check_launch("aau_bn_bwd_apply");
 }

@@ -38,13 +38,20 @@ def _ru(x, m):
 
 
 class _Rec:
-    """Recorded launch list.  Tensors are turned into raw pointers at record time and kept alive."""
+    """Recorded launch list.  Tensors are turned into raw pointers at record time and kept alive.
+
+    Ops can be tagged for a SIDE stream (weight gradients: they only feed the optimiser, so they run
+    concurrently with the data-gradient / BatchNorm chain that the next layer is waiting for).
+    ``fork`` makes the side stream wait for everything recorded so far on the main stream; ``join``
+    makes the main stream wait for the side stream."""
 
     def __init__(self):
         self.ops = []
         self.keep = []
+        self.side = None        # torch.cuda.Stream, created on first use
+        self.uses_side = False
 
-    def add(self, name, *args):
+    def add(self, name, *args, side=False):
         f = _abi.fn(name)
         conv = []
         for a in args:
@@ -56,17 +63,38 @@ class _Rec:
                 conv.append(C.byref(a))
             else:
                 conv.append(a)
-        self.ops.append((f, tuple(conv), name))
+        self.ops.append((f, tuple(conv), name, 1 if side else 0))
+        self.uses_side |= side
 
     def callback(self, fn: Callable[[], None]):
-        self.ops.append((None, fn, "callback"))
+        self.ops.append((None, fn, "callback", 0))
+
+    def fork(self):
+        self.ops.append((None, None, "fork", 0))
+
+    def join(self):
+        self.ops.append((None, None, "join", 0))
 
     def run(self, stream: int):
-        for f, a, name in self.ops:
+        side_t = side = None
+        if self.uses_side:
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            side_t = self.side
+            side = side_t.cuda_stream
+            main_t = torch.cuda.current_stream()
+        for f, a, name, sid in self.ops:
             if f is None:
-                a()
+                if name == "fork":
+                    if side_t is not None:
+                        side_t.wait_stream(main_t)
+                elif name == "join":
+                    if side_t is not None:
+                        main_t.wait_stream(side_t)
+                else:
+                    a()
                 continue
-            rc = f(*a, stream)
+            rc = f(*a, side if sid else stream)
             if rc != 0:
                 _abi.check(rc, name)
 
@@ -305,16 +333,27 @@ class Plan:
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
         dz = self.new(M, cv.O)
-        b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, dpool, dpp, dz, cv.O, w["scale"], w["shift"], w["mean"],
-              w["invstd"], w["red"], N, H, W, cv.O, 1, self.drop_p if r["drop"] else 0.0, self.drop_seed)
-        b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
-              bn.dbeta, M, cv.O)
+        dp_ = self.drop_p if r["drop"] else 0.0
+        if dpool is None:
+            # no pooling: the reduce pass only accumulates, the apply pass recomputes the ReLU / dropout mask
+            b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"], w["mean"],
+                  w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
+            b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
+                  bn.dbeta, M, cv.O, dy, dyp, w["scale"], w["shift"], 1, dp_, self.drop_seed)
+        else:
+            b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, dpool, dpp, dz, cv.O, w["scale"], w["shift"], w["mean"],
+                  w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
+            b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
+                  bn.dbeta, M, cv.O, None, 0, None, None, 1, 0.0, self.drop_seed)
         pad = cv.dil * (cv.k // 2)
+        ov = self.eng.overlap_wgrad
+        if ov:
+            b.fork()            # dz is final: the weight gradient can run beside the data-gradient chain
         if cv.kind == "first":
-            b.add("aau_conv1_wgrad", r["src"], dz, cv.dw, N, H, W, cv.O)
+            b.add("aau_conv1_wgrad", r["src"], dz, cv.dw, N, H, W, cv.O, side=ov)
             return dz
         dwd = ops.conv_desc(N, H, W, cv.I, r["sp"], H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil)
-        b.add("aau_conv_wgrad", dwd, r["src"], dz, cv.dw)
+        b.add("aau_conv_wgrad", dwd, r["src"], dz, cv.dw, side=ov)
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate)
@@ -470,9 +509,13 @@ class Plan:
                       gt["bx"].gamma, wxb["mean"], wxb["invstd"], wxb["red"], dzg, dzx, gt["bg"].dgamma,
                       gt["bg"].dbeta, gt["bx"].dgamma, gt["bx"].dbeta, Mo, Fi)
                 wg, wx = gt["wg"], gt["wx"]
-                b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], dzg, wg.dw)
+                ov = eng.overlap_wgrad
+                if ov:
+                    b.fork()
+                b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], dzg, wg.dw,
+                      side=ov)
                 b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], dzx,
-                      wx.dw)
+                      wx.dw, side=ov)
                 b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, 2 * Co, Cpad=wg.cpad_d,
                                                       accumulate=1), dzg, wg.pk_d, dcat[:, Co:], None, None, None,
                       None)
@@ -481,8 +524,11 @@ class Plan:
             # ConvTranspose2d backward: bias, weight, input
             gsrc, gc = blk["g_in"], blk["g_c"]
             b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, rep_ws, Mo, Co)
+            ov = eng.overlap_wgrad
+            if ov:
+                b.fork()        # dcat[:, Co:] is final (gate data-gradient accumulated above)
             b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1),
-                  dcat[:, Co:], gsrc, up.dw)
+                  dcat[:, Co:], gsrc, up.dw, side=ov)
             dg_in = self.new(B * hi * wi, gc)
             b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1, up.cpad_d),
                   dcat[:, Co:], up.pk_d, dg_in, None, None, None, None)
@@ -523,7 +569,10 @@ class Plan:
     def _mark(self, name):
         cb = self.eng.bucket_callback(name)
         if cb is not None:
+            self.bwd.join()          # the bucket's weight gradients run on the side stream
             self.bwd.callback(cb)
+        elif name == "d1":
+            self.bwd.join()          # end of backward: everything is back on the main stream
 
     # ---- execution ----
     def run_forward(self, x: torch.Tensor):
@@ -556,6 +605,8 @@ class Engine:
         self.plans: dict = {}
         self._seed = 0x5EED
         self.bucket_cb = None   # set by the data-parallel wrapper: name -> callable
+        import os
+        self.overlap_wgrad = os.environ.get("AAU_OVERLAP_WGRAD", "0") == "1"   # measured null on MI355X (A/B, same device)
 
     def next_seed(self) -> int:
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
@@ -585,7 +636,7 @@ class Engine:
 
     def plan(self, B, H, W, train) -> Plan:
         key = (B, H, W, bool(train), float(self.model.bridge.project[3].p) if train else 0.0,
-               self.bucket_cb is not None)
+               self.bucket_cb is not None, self.overlap_wgrad)
         p = self.plans.get(key)
         if p is None:
             p = Plan(self, B, H, W, bool(train))

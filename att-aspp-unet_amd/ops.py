@@ -102,9 +102,11 @@ def bn_bwd_reduce(z, zp, dy, dyp, dpool, dpp, dz, dzp, scale, shift, smean, sinv
                                   _stream()), "aau_bn_bwd_reduce")
 
 
-def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, Cc):
+def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, Cc, dy=None, dyp=0, scale=None,
+                 shift=None, relu=1, drop_p=0.0, drop_seed=0):
     check(fn("aau_bn_bwd_apply")(_p(z), zp, _p(dz), dzp, _p(gamma), _p(smean), _p(sinvstd), _p(red),
-                                 _p(dgamma), _p(dbeta), M, Cc, _stream()), "aau_bn_bwd_apply")
+                                 _p(dgamma), _p(dbeta), M, Cc, _p(dy), dyp, _p(scale), _p(shift), relu, drop_p,
+                                 drop_seed, _stream()), "aau_bn_bwd_apply")
 
 
 def gap_fwd(x, xp, pooled, ws, N, HW, Cc):

@@ -153,10 +153,13 @@ int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16* dy, int dy
                       const float* scale, const float* shift, const float* save_mean,
                       const float* save_invstd, float* red, int N, int H, int W, int C,
                       int relu, float drop_p, uint64_t drop_seed, void* stream);
+/* Non-pooled layers may skip the intermediate: pass dz = NULL to the reduce pass and give */
+/* the apply pass dy (+ scale, shift, relu, dropout parameters); it recomputes the mask.   */
 int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
                      const float* gamma, const float* save_mean, const float* save_invstd,
                      const float* red, float* dgamma, float* dbeta, int64_t M, int C,
-                     void* stream);
+                     const aau_bf16* dy, int dy_pitch, const float* scale, const float* shift,
+                     int relu, float drop_p, uint64_t drop_seed, void* stream);
 
 /* ---- ASPP image-pool branch (pipeline:75-77,82) -------------------------------------- */
 /* ws: caller-provided fp32 [N*C] workspace (zeroed by the call)                        */

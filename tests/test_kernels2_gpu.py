@@ -126,6 +126,15 @@ def test_maxpool_and_bn_backward_with_pool_routing(ops, C):
     ops.bn_bwd_apply(zd, C, dz, C, dev(gamma), dev(mean.detach()), dev(invstd.detach()), red, None, None, N * H * W, C)
     torch.cuda.synchronize()
     assert rel_err(dz.cpu(), zc2.grad) < 2e-2
+    # same, without storing the masked gradient: reduce(dz=None) + apply(dy=...) recomputes the mask
+    red.zero_()
+    dz2 = zeros(N, H, W, C, dtype=torch.bfloat16)
+    ops.bn_bwd_reduce(zd, C, dev(bf(gy)), C, None, 0, None, C, scale, shift, dev(mean.detach()), dev(invstd.detach()),
+                      red, N, H, W, C, relu=1)
+    ops.bn_bwd_apply(zd, C, dz2, C, dev(gamma), dev(mean.detach()), dev(invstd.detach()), red, None, None, N * H * W, C,
+                     dy=dev(bf(gy)), dyp=C, scale=scale, shift=shift, relu=1)
+    torch.cuda.synchronize()
+    assert torch.equal(dz2.cpu(), dz.cpu())
 
 
 def test_dropout_mask_is_consistent_between_forward_and_backward(ops):
