@@ -51,16 +51,21 @@ __device__ __forceinline__ void wait_vm() {
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int BQ>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
+// PW = patch width in 16-pixel columns.  PW = 2 (512 threads, 16 x 32 patch, one workgroup per CU) shares
+// every weight tile and the halo between 8 waves: half the LDS-DMA instructions per wave and half the
+// weight traffic per FLOP at the same 2 waves per SIMD.
+template <int BQ, int PW>
+__global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
     constexpr int BK = 32;
-    constexpr int HW_ = 18;                 // halo width / height
-    constexpr int HROWS = HW_ * HW_;        // 324 halo pixels
-    constexpr int HPAD = 384;               // rows staged (24 wave-instructions of 16 rows)
+    constexpr int NWAVE = 4 * PW;
+    constexpr int HW_ = 16 * PW + 2;        // halo width
+    constexpr int HROWS = 18 * HW_;         // halo pixels: 324 / 612
+    constexpr int HL = (HROWS + 16 * NWAVE - 1) / (16 * NWAVE);   // halo LDS-DMA instructions per wave: 6 / 5
+    constexpr int HPAD = HL * NWAVE * 16;   // rows staged (rows >= HROWS are zero fill)
     constexpr int NI = BQ / 16;             // channel tiles per wave
     constexpr int MI = 4;                   // patch rows per wave
-    constexpr int WL = (BQ == 96) ? 2 : 1;  // weight-tile LDS-DMA instructions per wave
-    constexpr int HL = 6;                   // halo LDS-DMA instructions per wave
+    constexpr int WROWS = BQ / NWAVE;       // weight-tile rows staged by one wave: 24 / 12 / 6
+    constexpr int WL = (WROWS + 15) / 16;   // weight-tile LDS-DMA instructions per wave
     constexpr int NS = 3;                   // weight ring slots (deeper rings measured slower: not latency bound)
     constexpr int PD = NS - 1;              // weight tiles are issued PD steps ahead
     constexpr int HALO_E = HPAD * BK;       // elements
@@ -90,7 +95,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
     patch /= a.tiles_x;
     const int py_t = patch % a.tiles_y;
     const int n = patch / a.tiles_y;
-    const int q0 = tq * BQ, y0 = py_t * 16, x0 = px_t * 16;
+    const int q0 = tq * BQ, y0 = py_t * 16, x0 = px_t * 16 * PW;
+    const int wr = wave & 3, wcol = wave >> 2;   // wave -> 4 patch rows x one 16-pixel column
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
     const int tail_c0 = (a.nchunk - 1) * BK;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-        const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+        const int hr = (i * NWAVE + wave) * 16 + (lane >> 2);
         const int lc = swz32(hr, lane & 3);
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
@@ -111,7 +117,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
     }
     const bool has_tail = d.Cpad != d.Cin;
     // ---- weights: rows of this wave's share of the [BQ][32] tile ----
-    constexpr int WROWS = BQ / 4;  // rows per wave: 24 or 12
     unsigned woff[WL];
 #pragma unroll
     for (int j = 0; j < WL; ++j) {
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
             const unsigned v = (last && !htail[i]) ? OOB : hoff[i];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + (i * 4 + wave) * 16 * BK), 16, (int)v,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + (i * NWAVE + wave) * 16 * BK), 16, (int)v,
                                                      chunk * BK * 2, 0, 0);
         }
     };
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
         const unsigned short* hbase = sH(hb);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
+            const int hr = (wr * MI + mi + ty) * HW_ + wcol * 16 + fr + tx;
             af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
         }
     };
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const C3Args a) {
         for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int y = y0 + wave * MI + mi, x = x0 + fr;
+        const int y = y0 + wr * MI + mi, x = x0 + wcol * 16 + fr;
         const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -561,10 +566,15 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
             return check_launch("aau_conv_igemm(3x3 resident weights)");
         }
     }
+    // 16 x 32 patches with 8 waves (one workgroup per CU) halve the LDS-DMA instructions per wave, but
+    // measured 8-12 % SLOWER than two 4-wave workgroups per CU (A/B on one device): opt-in only
+    const bool wide_patch = !narrow && d->W % 32 == 0 && getenv("AAU_C3_PW2");
+    if (wide_patch) a.tiles_x = d->W / 32;
     const int64_t grid = (int64_t)((d->Cout + BQ - 1) / BQ) * a.tiles_x * a.tiles_y * d->N;
     if (grid <= 0 || grid > 0x7fffffff) { set_error("conv3x3: grid out of range"); return AAU_E_INVALID; }
-    if (narrow) hipLaunchKernelGGL((conv3x3_kernel<48>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_kernel<96>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    if (narrow) hipLaunchKernelGGL((conv3x3_kernel<48, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (wide_patch) hipLaunchKernelGGL((conv3x3_kernel<96, 2>), dim3((unsigned)grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_kernel<96, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return check_launch("aau_conv_igemm(3x3 halo)");
 }
 

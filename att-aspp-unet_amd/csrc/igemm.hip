@@ -47,14 +47,18 @@ struct IgemmArgs {
     unsigned wpk_bytes;
 };
 
-template <int BK, int BQ>
+// SMALL = half-height pixel tile (64 x 96): for the 32x32-resolution layers (M = 8192) the regular tiling
+// yields only 256 workgroups (one per CU, 1 wave per SIMD); 512 smaller ones hide twice the latency.
+template <int BK, int BQ, bool SMALL = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
-    constexpr int BP = (BQ == 96) ? 128 : 256;
+    constexpr int BP = SMALL ? 64 : ((BQ == 96) ? 128 : 256);
+    static_assert(!SMALL || BQ == 96, "the small tile is a 2x2 wave layout");
     constexpr int SLOTS = BK / 8;            // 16-B slots per LDS row
     constexpr int RPI = 64 / SLOTS;          // rows covered by one wave-wide glds
     constexpr int NA = BP / (4 * RPI);       // activation loads per thread per K-step
     constexpr int NW = (BQ + 4 * RPI - 1) / (4 * RPI);  // weight loads per thread (last may be partial)
-    constexpr int MI = 4, NI = 3;            // wave tile: 64 pixels x 48 channels
+    constexpr int MI = SMALL ? 2 : 4, NI = 3; // wave tile: 64 (32) pixels x 48 channels
+    constexpr int WPX = MI * 16;
     constexpr int KSUB = BK / 32;
 
     __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BQ + BP) * BK];
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                const int row = wp * 64 + mi * 16 + fr;
+                const int row = wp * WPX + mi * 16 + fr;
                 af[mi] = *(const bf16x8*)(sA(buf) + row * BK + swz<BK>(row, kk * 4 + fk) * 8);
             }
 #pragma unroll
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wp * 64 + mi * 16 + fr;
+        const int m = m0 + wp * WPX + mi * 16 + fr;
         const bool mok = m < a.M;
         int64_t pixel = m;
         int n = 0, yo = 0, xo = 0;
@@ -350,9 +354,9 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
                    hipStream_t s);
 
-template <int BK, int BQ>
+template <int BK, int BQ, bool SMALL = false>
 static int launch(const IgemmArgs& a, hipStream_t s) {
-    constexpr int BP = (BQ == 96) ? 128 : 256;
+    constexpr int BP = SMALL ? 64 : ((BQ == 96) ? 128 : 256);
     const int ntq = (a.d.Cout + BQ - 1) / BQ;
     const int ntp = (a.M + BP - 1) / BP;
     const int64_t grid = (int64_t)ntq * ntp;
@@ -360,7 +364,7 @@ static int launch(const IgemmArgs& a, hipStream_t s) {
         set_error("aau_conv_igemm: grid %lld out of range", (long long)grid);
         return AAU_E_INVALID;
     }
-    hipLaunchKernelGGL((igemm_kernel<BK, BQ>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((igemm_kernel<BK, BQ, SMALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return check_launch("aau_conv_igemm");
 }
 
@@ -406,6 +410,9 @@ extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const
         return conv3x3_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes,
                               (hipStream_t)stream);
     const bool narrow = d->Cout <= 48;
+    // long-K, few-tile problems (bridge at 32x32): halve the pixel tile to double the workgroup count
+    const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((d->Cout + 95) / 96);
+    if (bk64 && !narrow && tiles128 <= 384 && a.nchunk * d->KH * d->KW >= 16) return launch<64, 96, true>(a, (hipStream_t)stream);
     if (bk64) return narrow ? launch<64, 48>(a, (hipStream_t)stream) : launch<64, 96>(a, (hipStream_t)stream);
     return narrow ? launch<32, 48>(a, (hipStream_t)stream) : launch<32, 96>(a, (hipStream_t)stream);
 }
