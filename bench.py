@@ -179,8 +179,18 @@ def main():
         conv_ms = (prof["igemm"]["ms"] + prof["wgrad"]["ms"]) / nprof
         alg = train_gflop_per_image(a.base_c, a.size) * a.batch * 1e9
         achieved = alg / (conv_ms * 1e-3) / 1e12
+        # HBM traffic of the conv launches: PMC passes (FETCH_SIZE, WRITE_SIZE in separate rocprofv3 runs of this
+        # very command, corrected as MI355X_MICROARCH.md prescribes) are stored under profiles/; bytes per launch
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if a.base_c == 48 and a.size == 512 and a.batch == 8:
+                traffic = pm["conv_kernels"]["bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "kernel": "igemm_kernel + wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad)",
                 "launches_per_step": (prof["igemm"]["launches"] + prof["wgrad"]["launches"]) // nprof,
                 "avg_launch_ms": conv_ms / max(1, (prof["igemm"]["launches"] + prof["wgrad"]["launches"]) // nprof),
