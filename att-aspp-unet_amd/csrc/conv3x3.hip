@@ -330,6 +330,228 @@ __global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Grouped-tap variant of the halo kernel: a pipeline step covers 2 taps (groups {0,1} {2,3} {4,5} {6,7} {8})
+// instead of one, so a 32-channel chunk costs 5 barriers / waits / fragment-latency exposures instead of 9,
+// with 48 MFMAs per wave between them.  Weight ring: 2 slots of 2 tap tiles, halo rows trimmed to 336:
+// 67 KB, two workgroups per CU as before.
+template <int BQ>
+__global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
+    constexpr int BK = 32, HW_ = 18, HROWS = 324, HPAD = 336, NI = BQ / 16, MI = 4;
+    constexpr int WROWS = BQ / 4, WL = (WROWS + 15) / 16, WLAST = WROWS - (WL - 1) * 16;
+    constexpr int HALO_E = HPAD * BK, WT_E = BQ * BK, SLOT_E = 2 * WT_E;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HALO_E + 2 * SLOT_E];
+    auto sH = [&](int b) -> unsigned short* { return smem + b * HALO_E; };
+    auto sWt = [&](int slot, int k) -> unsigned short* { return smem + 2 * HALO_E + slot * SLOT_E + k * WT_E; };
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int ntq = (d.Cout + BQ - 1) / BQ;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tq = bid % ntq;
+    int patch = bid / ntq;
+    const int px_t = patch % a.tiles_x;
+    patch /= a.tiles_x;
+    const int py_t = patch % a.tiles_y;
+    const int n = patch / a.tiles_y;
+    const int q0 = tq * BQ, y0 = py_t * 16, x0 = px_t * 16;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+
+    // halo roles: 21 wave-instructions of 16 rows; wave 0 issues 6, the others 5
+    const int hl = (wave == 0) ? 6 : 5;
+    unsigned hoff[6];
+    bool htail[6];
+    const int tail_c0 = (a.nchunk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+        const int lc = swz32(hr, lane & 3);
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = hr < HROWS && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+        hoff[i] = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc * 8) * 2) : OOB;
+        htail[i] = tail_c0 + lc * 8 < d.Cin;
+    }
+    const bool has_tail = d.Cpad != d.Cin;
+    unsigned woff[WL];
+#pragma unroll
+    for (int j = 0; j < WL; ++j) {
+        const int row = wave * WROWS + j * 16 + (lane >> 2);
+        const int lc = swz32(row, lane & 3);
+        const bool ok = (j * 16 + (lane >> 2)) < WROWS && (q0 + row) < d.Cout;
+        woff[j] = ok ? (unsigned)(((q0 + row) * 9 * d.Cpad + lc * 8) * 2) : OOB;
+    }
+    auto issue_halo = [&](int chunk) {
+        const bool last = has_tail && chunk == a.nchunk - 1;
+        unsigned short* base = sH(chunk & 1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i < hl) {   // wave-uniform
+                const unsigned v = (last && !htail[i]) ? OOB : hoff[i];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + (i * 4 + wave) * 16 * BK), 16, (int)v,
+                                                         chunk * BK * 2, 0, 0);
+            }
+        }
+    };
+    // group g of a chunk = taps {2g, 2g+1} for g < 4, {8} for g == 4
+    auto issue_w = [&](int slot, int chunk, int g) {
+        const int t0 = 2 * g, nt = (g == 4) ? 1 : 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k < nt) {
+                const int soff = ((t0 + k) * d.Cpad + chunk * BK) * 2;
+                unsigned short* base = sWt(slot, k) + wave * WROWS * BK;
+#pragma unroll
+                for (int j = 0; j < WL; ++j) {
+                    if (j < WL - 1) {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(base + j * 16 * BK), 16, (int)woff[j], soff, 0, 0);
+                    } else if (lane < WLAST * 4) {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(base + j * 16 * BK), 16, (int)woff[j], soff, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+    auto compute_tap = [&](const unsigned short* hbase, const unsigned short* wbase, int tap) {
+        const int ty = tap / 3, tx = tap - ty * 3;
+        bf16x8 wf[NI], af[MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = ni * 16 + fr;
+            wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
+            af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+    // ---- pipeline over S = nchunk * 5 steps; weights one step ahead, next halo issued AFTER them at group 0 ----
+    const int S = a.nchunk * 5;
+    issue_halo(0);
+    issue_w(0, 0, 0);
+    int chunk = 0, g = 0, slot = 0;
+    bool halo_prev = false;     // the previous step issued a halo tile (after its weight tiles)
+    for (int s = 0; s < S; ++s) {
+        if (halo_prev) {        // only that halo tile may stay in flight
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        halo_prev = false;
+        if (s + 1 < S) {
+            int g2 = g + 1, c2 = chunk;
+            if (g2 == 5) { g2 = 0; ++c2; }
+            issue_w(slot ^ 1, c2, g2);
+        }
+        if (g == 0 && chunk + 1 < a.nchunk) { issue_halo(chunk + 1); halo_prev = true; }
+        const unsigned short* hbase = sH(chunk & 1);
+        compute_tap(hbase, sWt(slot, 0), 2 * g);
+        if (g < 4) compute_tap(hbase, sWt(slot, 1), 2 * g + 1);
+        if (++g == 5) { g = 0; ++chunk; }
+        slot ^= 1;
+    }
+
+    // ---- epilogue (as conv3x3_kernel) ----
+    const bool want_stats = a.stats != nullptr;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int y = y0 + wave * MI + mi, x = x0 + fr;
+        const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int q = q0 + ni * 16 + 4 * fk;
+            if (q >= d.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+            if (want_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1[ni][r] += v[r]; s2[ni][r] += v[r] * v[r]; }
+            }
+            if (a.bias) {
+                const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (a.scale) {
+                const f32x4 sc = *(const f32x4*)(a.scale + q);
+                const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+            }
+            unsigned short* out = a.dst + pixel * d.dst_pitch + q;
+            if (d.accumulate) {
+                const u32x2 old = *(const u32x2*)out;
+                v[0] += __uint_as_float(old[0] << 16);
+                v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                v[2] += __uint_as_float(old[1] << 16);
+                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+            }
+            if (d.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            u32x2 pk;
+            pk[0] = pack2(v[0], v[1]);
+            pk[1] = pack2(v[2], v[3]);
+            *(u32x2*)out = pk;
+        }
+    }
+    if (want_stats) {
+        float* sst = (float*)smem;
+        __syncthreads();
+        if (tid < 2 * BQ) sst[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0) {
+                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
+                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                }
+            }
+        }
+        __syncthreads();
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        if (tid < 2 * BQ) {
+            const int which = tid / BQ, ql = tid - which * BQ;
+            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Resident-weight variant for the high-resolution, few-channel layers (d1.1, d2.0, u1.conv.*):
 // there the whole packed weight matrix of a channel tile (<= 110 KB) fits in LDS next to two halo
 // buffers, K is short (18-27 steps) and the per-workgroup prologue / epilogue of the kernel above
@@ -572,6 +794,11 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     if (wide_patch) a.tiles_x = d->W / 32;
     const int64_t grid = (int64_t)((d->Cout + BQ - 1) / BQ) * a.tiles_x * a.tiles_y * d->N;
     if (grid <= 0 || grid > 0x7fffffff) { set_error("conv3x3: grid out of range"); return AAU_E_INVALID; }
+    if (!wide_patch && !getenv("AAU_C3_NOGROUP")) {
+        if (narrow) hipLaunchKernelGGL((conv3x3g_kernel<48>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3g_kernel<96>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        return check_launch("aau_conv_igemm(3x3 halo, grouped taps)");
+    }
     if (narrow) hipLaunchKernelGGL((conv3x3_kernel<48, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else if (wide_patch) hipLaunchKernelGGL((conv3x3_kernel<96, 2>), dim3((unsigned)grid), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv3x3_kernel<96, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
