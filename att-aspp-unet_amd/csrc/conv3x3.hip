@@ -440,11 +440,15 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
             const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
             af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
         }
+        // raised priority keeps the MFMA cluster together (A/B: +3-7 % here; the same pair costs
+        // wgrad3x3_kernel 6-9 %, so it is not used there)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- pipeline over S = nchunk * 5 steps; weights one step ahead, next halo issued AFTER them at group 0 ----
@@ -673,11 +677,17 @@ __global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int n
                     const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
                     af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
                 }
+#ifdef AAU_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
                         acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#ifdef AAU_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
         }
         // ---- per-patch epilogue ----

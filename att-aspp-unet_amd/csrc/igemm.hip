@@ -208,11 +208,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 const int row = wp * WPX + mi * 16 + fr;
                 af[mi] = *(const bf16x8*)(sA(buf) + row * BK + swz<BK>(row, kk * 4 + fk) * 8);
             }
+#ifdef AAU_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#ifdef AAU_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     };
 

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
 #pragma unroll
                     for (int i = 0; i < QT; ++i)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+
                 }
             }
         }
