@@ -20,6 +20,17 @@ namespace aau {
 // 16-B loads of out-of-image taps / rows past the tensor are redirected to this page
 static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
+// Reduction workspaces are cleared by a kernel, never hipMemsetAsync: a memset node captured into a hipGraph
+// stopped taking effect once the same range had been cleared by an eager hipMemsetAsync (ROCm 7.2, gfx950;
+// scripts/debug_stale.py), which fed garbage partial sums to the replayed forward.
+static __global__ void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+static inline void zero_f32(float* p, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+}
+
 // ---- bf16 <-> f32 (round to nearest even; plain casts keep NaN a NaN, see guide) ----
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {

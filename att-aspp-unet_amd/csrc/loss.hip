@@ -222,7 +222,7 @@ extern "C" int aau_criterion(const float* logits, const float* targets, float* s
                 "aau_criterion: bad args");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(3, 0, s);
-    hipMemsetAsync(sums, 0, (size_t)NREP * B * NS * sizeof(float), s);
+    zero_f32(sums, (int64_t)NREP * B * NS, s);
     dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
     hipLaunchKernelGGL(crit_reduce_kernel, grid, dim3(256), 0, s, logits, targets, sums, H, W, 0.f,
                        edge_w > 0.f ? 1 : 0);
@@ -242,7 +242,7 @@ extern "C" int aau_seg_metrics(const float* logits, const float* targets, float*
     AAU_REQUIRE(thr > 0.f && thr < 1.f, "aau_seg_metrics: thr=%f must be in (0,1)", thr);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(3, 0, s);
-    hipMemsetAsync(sums, 0, (size_t)NREP * B * NS * sizeof(float), s);
+    zero_f32(sums, (int64_t)NREP * B * NS, s);
     dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
     const float thr_logit = logf(thr / (1.f - thr));  // sigmoid(l) > thr  <=>  l > logit(thr)
     hipLaunchKernelGGL(crit_reduce_kernel, grid, dim3(256), 0, s, logits, targets, sums, H, W, thr_logit, 0);

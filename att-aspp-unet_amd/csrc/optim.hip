@@ -108,7 +108,7 @@ extern "C" int aau_grad_sqnorm(const float* grad, int64_t n, float inv_scale, fl
     AAU_REQUIRE(((uintptr_t)grad & 15) == 0, "aau_grad_sqnorm: grad must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(3, 0, s);
-    hipMemsetAsync(norm_ws, 0, sizeof(float), s);
+    zero_f32(norm_ws, 1, s);
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;

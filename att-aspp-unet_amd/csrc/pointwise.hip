@@ -412,7 +412,7 @@ extern "C" int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlog
     int64_t blocks, ppb;
     split_rows(M, mp.PL, 16, 2048, &blocks, &ppb);
     ProfScope prof(2, 4.0 * M * C, (hipStream_t)stream);
-    hipMemsetAsync(ws, 0, (size_t)AAU_STAT_REPLICAS * (C + 8) * sizeof(float), (hipStream_t)stream);
+    zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * (C + 8), (hipStream_t)stream);
     hipLaunchKernelGGL(outconv_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, y_pitch,
                        dlogits, w, dy, dy_pitch, ws, M, C, ppb);
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, dw, C,
@@ -423,7 +423,7 @@ extern "C" int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlog
 static int spatial_reduce(const aau_bf16* src, int sp, aau_bf16* out, int N, int HW, int C, float alpha,
                           float* ws, hipStream_t s) {
     const int64_t need = (int64_t)N * C;
-    hipMemsetAsync(ws, 0, need * sizeof(float), s);
+    zero_f32(ws, need, s);
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows(HW, mp.PL, 8, 64, &blocks, &ppb);
@@ -464,7 +464,7 @@ extern "C" int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float*
     int64_t blocks, ppb;
     split_rows(M, mp.PL, 16, 1024, &blocks, &ppb);
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipMemsetAsync(ws, 0, (size_t)AAU_STAT_REPLICAS * (C + 8) * sizeof(float), (hipStream_t)stream);
+    zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * (C + 8), (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, src_pitch, ws, M,
                        C, ppb);
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, out, C,

@@ -1,0 +1,36 @@
+"""Race screen: repeat deterministic launches (no atomics / no stats) and compare outputs bitwise."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from att_aspp_unet_amd import ops
+torch.manual_seed(0)
+def run_case(name, N, H, W, Ci, Co, k, dil, reps=40, extra=None):
+    x = torch.randn(N, H, W, Ci, device="cuda").to(torch.bfloat16)
+    cp = ops.cpad_of(Ci)
+    w = (torch.randn(Co, k * k, cp, device="cuda") / (Ci * k * k) ** 0.5).to(torch.bfloat16)
+    if cp != Ci: w[:, :, Ci:] = 0
+    d = ops.conv_desc(N, H, W, Ci, Ci, H, W, Co, Co, k, k, 1, dil * (k // 2), dil, cp)
+    outs = []
+    other = torch.randn(64 << 20, device="cuda")  # background traffic between launches changes timing
+    for r in range(reps):
+        out = torch.full((N, H, W, Co), float("nan"), dtype=torch.bfloat16, device="cuda")
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_igemm(d, x, w, out)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(out)
+    torch.cuda.synchronize()
+    bad = sum(0 if torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) else 1 for o in outs[1:])
+    nan = int(torch.isnan(outs[0].float()).sum())
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {nan}", flush=True)
+    return bad
+tot = 0
+tot += run_case("conv3x3g<96> 64x64 768->384", 8, 64, 64, 768, 384, 3, 1)
+tot += run_case("conv3x3g<96> 128x128 96->192", 8, 128, 128, 96, 192, 3, 1)
+tot += run_case("conv3x3g<48> small 48->48", 2, 64, 64, 48, 48, 3, 1)
+tot += run_case("resw<48> 512 48->48", 8, 512, 512, 48, 48, 3, 1, reps=12)
+tot += run_case("resw<48> 512 96->48", 8, 512, 512, 96, 48, 3, 1, reps=12)
+tot += run_case("resw<96> 256 48->96", 8, 256, 256, 48, 96, 3, 1, reps=12)
+tot += run_case("igemm dil6 32x32 384->768", 8, 32, 32, 384, 768, 3, 6)
+tot += run_case("igemm SMALL dgrad-like 768->384 d12", 8, 32, 32, 768, 384, 3, 12)
+tot += run_case("igemm 1x1 3840->768", 8, 32, 32, 3840, 768, 1, 1)
+tot += run_case("igemm 1x1 96->48 256", 8, 256, 256, 96, 48, 1, 1, reps=12)
+print("TOTAL mismatches", tot)
