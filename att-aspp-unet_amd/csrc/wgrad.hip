@@ -18,9 +18,17 @@
 // runs) into the channels_last gradient [Cout][taps][Cin], which the caller zeroes.
 //
 // Replaces the weight part of ATen convolution_backward for pipeline:63,71-78,88-89,101.
+#include <stdlib.h>
 #include "common.h"
 
 namespace aau {
+
+// timing-only ablation: -DABL_NOATOMIC turns the split-K adds into plain stores (wrong sums)
+#ifdef ABL_NOATOMIC
+#define WG_ADD(p, v) (*(p) = (v))
+#else
+#define WG_ADD(p, v) atomicAdd((p), (v))
+#endif
 
 
 struct WgradArgs {
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + wq * 48 + i * 16 + 4 * g16 + r;
                 if (q < d.Cout && c < d.Cin)
-                    atomicAdd(a.dw + ((int64_t)q * T + tap) * d.Cin + c, acc[i][j][r]);
+                    WG_ADD(a.dw + ((int64_t)q * T + tap) * d.Cin + c, acc[i][j][r]);
             }
         }
 }
@@ -236,8 +244,13 @@ static int launch(WgradArgs& a, hipStream_t s) {
     const aau_conv_desc& d = a.d;
     const int T = d.KH * d.KW;
     const int64_t tiles = (int64_t)((d.Cout + 48 * TQ - 1) / (48 * TQ)) * ((d.Cin + 48 * TC - 1) / (48 * TC)) * T;
-    // enough splits to give the chip ~8 workgroups per CU, at least 4 K-steps each
-    int64_t want = (2048 + tiles - 1) / tiles;
+    // Split-K: each split ends with a tile of fp32 atomics (memory side, ~1.3 TB/s chip-wide, slower still when
+    // many workgroups hit the same few rows), so the split count is a trade against occupancy.  Measured per
+    // shape on one device: 1x1 / 2x2 problems (K-steps are cheap, atomics dominate: -50 % time going from 2048
+    // to 512 workgroups, 256 when the whole matrix is one or two tiles); dilated 3x3 keeps 2048.
+    int64_t tgt = T >= 9 ? 2048 : (T == 1 && tiles <= 8 ? 256 : 512);
+    if (const char* e = getenv("AAU_WG_TARGET")) tgt = atoi(e);   // experiment
+    int64_t want = (tgt + tiles - 1) / tiles;
     int64_t maxsplit = (a.M + 4 * BKP - 1) / (4 * BKP);
     int64_t nsplit = want < 1 ? 1 : (want > maxsplit ? maxsplit : want);
     if (nsplit < 1) nsplit = 1;

@@ -23,6 +23,13 @@
 
 namespace aau {
 
+// timing-only ablation: -DABL_NOATOMIC turns the split-K adds into plain stores (wrong sums)
+#ifdef ABL_NOATOMIC
+#define WG_ADD(p, v) (*(p) = (v))
+#else
+#define WG_ADD(p, v) atomicAdd((p), (v))
+#endif
+
 struct W3Args {
     aau_conv_desc d;
     const unsigned short* src;   // x   [N][H][W] pitch src_pitch, Cin channels
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + i * 16 + 4 * g16 + r;
-                if (q < d.Cout && c < d.Cin) atomicAdd(a.dw + ((int64_t)q * 9 + tap) * d.Cin + c, acc[i][n][r]);
+                if (q < d.Cout && c < d.Cin) WG_ADD(a.dw + ((int64_t)q * 9 + tap) * d.Cin + c, acc[i][n][r]);
             }
     }
 }
@@ -219,10 +226,12 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, int64_t npix, hipStream_
     a.tiles_y = d->H / PR;
     a.npatch = d->N * a.tiles_x * a.tiles_y;
     const int64_t tiles = (int64_t)((d->Cout + BQ - 1) / BQ) * ((d->Cin + 47) / 48);
-    // every workgroup ends with BQ x 432 fp32 atomics (chip-wide ~1.3 TB/s): keep the grid near one or two
-    // resident rounds of workgroups (2 per CU) so the atomic traffic stays well below the MFMA time
-    const double flops = 2.0 * npix * (double)d->Cout * d->Cin * 9.0;
-    const int64_t target = flops >= 1.5e11 ? 1024 : 512;
+    // Every workgroup ends with BQ x 432 fp32 atomics, which execute at the memory side at ~1.3 TB/s chip-wide and
+    // are NOT hidden behind other workgroups once the whole grid is resident: a plain-store ablation of this
+    // epilogue (-DABL_NOATOMIC) is 20-35 us faster per launch.  One resident round (2 workgroups per CU) is the
+    // measured optimum for every layer; 1024 cost +15-30 % on the 174-GFLOP layers, 256 +30 % on the others.
+    int64_t target = 512;
+    if (const char* e = getenv("AAU_W3_TARGET")) target = atoi(e);   // experiment
     int64_t nsplit = (target + tiles / 2) / tiles;
     const int64_t maxsplit = (a.npatch + 3) / 4;             // at least 4 K-steps per workgroup
     if (nsplit > maxsplit) nsplit = maxsplit;

@@ -66,4 +66,75 @@ for name, H, Ci, Co, k, dil in LAYERS:
         tot["wgrad"] += t
         line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     print(line, flush=True)
+# ---- ConvTranspose2d(2,2) of the decoder (engine.py: forward = GEMM + pixel-shuffle store into the cat buffer's
+# upper half; backward = 2x2 stride-2 conv over the fine gradient) and the gate 1x1 convs with their strided /
+# accumulating operands ----
+UPS = [("u1.up", 256, 96, 48), ("u2.up", 128, 192, 96), ("u3.up", 64, 384, 192), ("u4.up", 32, 768, 384)]
+for name, hi, gc, Co in UPS:
+    if a.only and a.only not in name:
+        continue
+    ho = 2 * hi
+    Mi, Mo = B * hi * hi, B * ho * ho
+    gf = 2.0 * Mi * gc * 4 * Co / 1e9
+    g = torch.randn(Mi, gc, device="cuda").to(torch.bfloat16)
+    cat = torch.randn(Mo, 2 * Co, device="cuda").to(torch.bfloat16)
+    line = f"{name:8s} {gf:7.1f} GF"
+    if "fwd" in tot:
+        cp = ops.cpad_of(gc)
+        w = (torch.randn(4 * Co, 1, cp, device="cuda") / gc ** 0.5).to(torch.bfloat16)
+        bias = torch.zeros(Co, device="cuda")
+        d = ops.conv_desc(B, hi, hi, gc, gc, hi, hi, 4 * Co, 2 * Co, Cpad=cp, shuffle2x2=1)
+        t = timeit(lambda: ops.conv_igemm(d, g, w, cat[:, Co:], bias=bias))
+        tot["fwd"] += t
+        line += f" | fwd {t:7.1f} us {gf / t * 1e3:6.0f} TF"
+    if "dgrad" in tot:
+        cp = ops.cpad_of(Co)
+        w = (torch.randn(gc, 4, cp, device="cuda") / (4 * Co) ** 0.5).to(torch.bfloat16)
+        out = torch.empty(Mi, gc, device="cuda", dtype=torch.bfloat16)
+        d = ops.conv_desc(B, ho, ho, Co, 2 * Co, hi, hi, gc, gc, 2, 2, 2, 0, 1, cp)
+        t = timeit(lambda: ops.conv_igemm(d, cat[:, Co:], w, out))
+        tot["dgrad"] += t
+        line += f" | dgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
+    if "wgrad" in tot:
+        dw = torch.zeros(gc, 4, Co, device="cuda")
+        d = ops.conv_desc(B, ho, ho, Co, 2 * Co, hi, hi, gc, gc, 2, 2, 2, 0, 1)
+        t = timeit(lambda: ops.conv_wgrad(d, cat[:, Co:], g, dw))
+        tot["wgrad"] += t
+        line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
+    print(line, flush=True)
+GATES = [("u2.gate", 256, 96), ("u3.gate", 128, 192), ("u4.gate", 64, 384)]
+for name, ho, Co in GATES:
+    if a.only and a.only not in name:
+        continue
+    Mo, Fi = B * ho * ho, Co // 2
+    gf = 2 * 2.0 * Mo * Co * Fi / 1e9          # Wg and Wx together
+    cat = torch.randn(Mo, 2 * Co, device="cuda").to(torch.bfloat16)
+    skip = torch.randn(Mo, Co, device="cuda").to(torch.bfloat16)
+    zg, zx = torch.randn(Mo, Fi, device="cuda").to(torch.bfloat16), torch.randn(Mo, Fi, device="cuda").to(torch.bfloat16)
+    line = f"{name:8s} {gf:7.1f} GF"
+    if "fwd" in tot:
+        cp = ops.cpad_of(Co)
+        w = (torch.randn(Fi, 1, cp, device="cuda") / Co ** 0.5).to(torch.bfloat16)
+        st = torch.zeros(32, 2, Fi, device="cuda")
+        d1 = ops.conv_desc(B, ho, ho, Co, 2 * Co, ho, ho, Fi, Fi, Cpad=cp)
+        d2 = ops.conv_desc(B, ho, ho, Co, Co, ho, ho, Fi, Fi, Cpad=cp)
+        t = timeit(lambda: (ops.conv_igemm(d1, cat[:, Co:], w, zg, stats=st), ops.conv_igemm(d2, skip, w, zx, stats=st)))
+        tot["fwd"] += t
+        line += f" | fwd {t:7.1f} us {gf / t * 1e3:6.0f} TF"
+    if "dgrad" in tot:
+        cp = ops.cpad_of(Fi)
+        w = (torch.randn(Co, 1, cp, device="cuda") / Fi ** 0.5).to(torch.bfloat16)
+        d1 = ops.conv_desc(B, ho, ho, Fi, Fi, ho, ho, Co, 2 * Co, Cpad=cp, accumulate=1)
+        d2 = ops.conv_desc(B, ho, ho, Fi, Fi, ho, ho, Co, Co, Cpad=cp, accumulate=1)
+        t = timeit(lambda: (ops.conv_igemm(d1, zg, w, cat[:, Co:]), ops.conv_igemm(d2, zx, w, skip)))
+        tot["dgrad"] += t
+        line += f" | dgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
+    if "wgrad" in tot:
+        dw = torch.zeros(Fi, 1, Co, device="cuda")
+        d1 = ops.conv_desc(B, ho, ho, Co, 2 * Co, ho, ho, Fi, Fi)
+        d2 = ops.conv_desc(B, ho, ho, Co, Co, ho, ho, Fi, Fi)
+        t = timeit(lambda: (ops.conv_wgrad(d1, cat[:, Co:], zg, dw), ops.conv_wgrad(d2, skip, zx, dw)))
+        tot["wgrad"] += t
+        line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
+    print(line, flush=True)
 print("totals (us):", {k: round(v, 1) for k, v in tot.items()})
