@@ -84,6 +84,18 @@ struct ProfScope {  // brackets one launch with events when profiling is on
     hipStream_t stream;
 };
 
+// split-K reduction shared by wgrad.hip / wgrad3x3.hip (kernel in wgrad.hip)
+struct WRedArgs {
+    const float* ws;
+    float* dw;
+    int64_t nslots;
+    int nsplit, P, NV;      // NV = accumulator vectors per thread of the producer (9 / 21 / 42)
+    int sub, kwaves;        // MODE 0: TQ*TC sub-tiles and K-waves of the producer workgroup
+    int TQ, TC, ntc, T;     // tile decode
+    int Cout, Cin;
+};
+int wg_reduce_launch(int mode, WRedArgs& r, hipStream_t s);
+
 }  // namespace aau
 
 #define AAU_REQUIRE(cond, ...)                      \

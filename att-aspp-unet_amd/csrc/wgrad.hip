@@ -40,6 +40,7 @@ struct WgradArgs {
     int pix_per_split;  // multiple of the K-step
     int nsplit;
     int linear;         // 1: gather(m) == m (1x1, stride 1, pad 0)
+    float* ws;          // split-K slabs [workgroup][9 acc tiles][256 threads][4] (null: fp32 atomics into dw)
 };
 
 // byte offset of (row, channel ch [multiple of 4]) in a [rows][48*TT] bf16 tile
@@ -89,7 +90,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
     const int mb = split * a.pix_per_split;
     const int me = min(a.M, mb + a.pix_per_split);
-    if (mb >= me) return;  // uniform
+    if (mb >= me) {  // uniform; never taken with the host's split sizes, but a slab must not stay unwritten
+        if (a.ws)
+            for (int v = 0; v < 9; ++v) *(f32x4*)(a.ws + ((int64_t)blockIdx.x * 9 * 256 + v * 256 + threadIdx.x) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
 
     const unsigned short* zero = (const unsigned short*)g_zero_page;
     const int dy = (tap / d.KW) * d.dil - d.pad, dx = (tap % d.KW) * d.dil - d.pad;
@@ -218,6 +223,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 
     // acc[i][j][r] = D[q = q0 + wq*48 + i*16 + 4*g16 + r][c = c0 + wc*48 + j*16 + li]
+    if (a.ws) {
+        // split-K partial: the accumulators leave in register layout (16 B per lane, 4 KiB per instruction and
+        // workgroup); wg_reduce_kernel sums the slabs of a tile in a fixed order -> bitwise reproducible dw
+        float* slab = a.ws + (int64_t)blockIdx.x * (9 * 256 * 4);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *(f32x4*)(slab + ((i * 3 + j) * 256 + tid) * 4) = acc[i][j];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -232,22 +247,126 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// Sum of the split-K slabs of wgrad_kernel (MODE 0) / wgrad3x3_kernel (MODE 1), added into dw.
+// One thread owns one accumulator vector (tile, v, source lane) and walks over its (split, K-wave) terms in a
+// fixed order; P threads share the walk (terms p, p+P, ...) and are combined through LDS in part order.
+
+template <int MODE>
+__global__ __launch_bounds__(256) void wg_reduce_kernel(const WRedArgs a) {
+    __shared__ f32x4 sm[256];
+    const int VPB = 256 / a.P;
+    const int part = threadIdx.x / VPB, sl = threadIdx.x - part * VPB;
+    const int64_t slot = (int64_t)blockIdx.x * VPB + sl;
+    const bool ok = slot < a.nslots;
+    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+    int lane = 0, s = 0, v = 0, tile = 0;
+    if (ok) {
+        if constexpr (MODE == 0) {
+            lane = (int)(slot & 63);
+            int64_t rest = slot >> 6;
+            s = (int)(rest % a.sub); rest /= a.sub;
+            v = (int)(rest % 9);
+            tile = (int)(rest / 9);
+            const int nterms = a.nsplit * a.kwaves;
+            auto term = [&](int t) -> f32x4 {
+                const int split = t / a.kwaves, wk = t - split * a.kwaves;
+                return *(const f32x4*)(a.ws + ((((int64_t)tile * a.nsplit + split) * 9 + v) * 256 + (wk * a.sub + s) * 64 + lane) * 4);
+            };
+            int t = part;
+            for (; t + 3 * a.P < nterms; t += 4 * a.P) {
+                const f32x4 t0 = term(t), t1 = term(t + a.P), t2 = term(t + 2 * a.P), t3 = term(t + 3 * a.P);
+                sum += t0; sum += t1; sum += t2; sum += t3;
+            }
+            for (; t < nterms; t += a.P) sum += term(t);
+        } else {
+            lane = (int)(slot & 255);          // source thread id
+            int64_t rest = slot >> 8;
+            v = (int)(rest % a.NV);
+            tile = (int)(rest / a.NV);
+            // 4 independent loads in flight per thread; the order of the additions stays fixed
+            const float* p0 = a.ws + (((int64_t)tile * a.nsplit * a.NV + v) * 256 + lane) * 4;
+            const int64_t sstride = (int64_t)a.NV * 256 * 4;
+            int split = part;
+            for (; split + 3 * a.P < a.nsplit; split += 4 * a.P) {
+                const f32x4 t0 = *(const f32x4*)(p0 + (int64_t)split * sstride);
+                const f32x4 t1 = *(const f32x4*)(p0 + (int64_t)(split + a.P) * sstride);
+                const f32x4 t2 = *(const f32x4*)(p0 + (int64_t)(split + 2 * a.P) * sstride);
+                const f32x4 t3 = *(const f32x4*)(p0 + (int64_t)(split + 3 * a.P) * sstride);
+                sum += t0; sum += t1; sum += t2; sum += t3;
+            }
+            for (; split < a.nsplit; split += a.P) sum += *(const f32x4*)(p0 + (int64_t)split * sstride);
+        }
+    }
+    if (a.P > 1) {
+        sm[threadIdx.x] = sum;
+        __syncthreads();
+        if (part != 0) return;
+        for (int p = 1; p < a.P; ++p) sum += sm[p * VPB + sl];
+    }
+    if (!ok) return;
+    if constexpr (MODE == 0) {
+        const int tap = tile % a.T;
+        const int t2 = tile / a.T;
+        const int tc = t2 % a.ntc, tq = t2 / a.ntc;
+        const int wq = (a.TQ == 2) ? ((a.TC == 2) ? (s >> 1) : s) : 0;
+        const int wc = (a.TC == 2) ? ((a.TQ == 2) ? (s & 1) : s) : 0;
+        const int i = v / 3, j = v - i * 3;
+        const int g16 = lane >> 4, li = lane & 15;
+        const int c = tc * 48 * a.TC + wc * 48 + j * 16 + li;
+        const int qb = tq * 48 * a.TQ + wq * 48 + i * 16 + 4 * g16;
+        if (c < a.Cin)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (qb + r < a.Cout) a.dw[((int64_t)(qb + r) * a.T + tap) * a.Cin + c] += sum[r];
+    } else {
+        const int QT = a.NV / 7;
+        const int wave = lane >> 6, l = lane & 63;
+        const int i = v / 7, n = v - i * 7;
+        if (n >= (wave < 3 ? 7 : 6)) return;
+        const int ct = 7 * wave + n;
+        const int tap = ct / 3, j = ct - tap * 3;
+        const int tc = tile % a.ntc, tq = tile / a.ntc;
+        const int g16 = l >> 4, li = l & 15;
+        const int c = tc * 48 + j * 16 + li;
+        const int qb = tq * QT * 16 + i * 16 + 4 * g16;
+        if (c < a.Cin)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (qb + r < a.Cout) a.dw[((int64_t)(qb + r) * 9 + tap) * a.Cin + c] += sum[r];
+    }
+}
+
+int wg_reduce_launch(int mode, WRedArgs& r, hipStream_t s) {
+    // enough threads to pull the slabs at memory speed: share each vector's walk among P threads when the
+    // tile count is small (level-1 layers: ONE tile, 512 splits)
+    int P = 1;
+    while (P < 16 && r.nslots * P < 65536 && 2 * P <= r.nsplit * (mode == 0 ? r.kwaves : 1)) P *= 2;
+    r.P = P;
+    const int VPB = 256 / P;
+    const int64_t grid = (r.nslots + VPB - 1) / VPB;
+    if (mode == 0) hipLaunchKernelGGL((wg_reduce_kernel<0>), dim3((unsigned)grid), dim3(256), 0, s, r);
+    else hipLaunchKernelGGL((wg_reduce_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, r);
+    return check_launch("aau_conv_wgrad(split-K reduce)");
+}
+
 // wgrad3x3.hip
 bool wgrad3x3_applicable(const aau_conv_desc* d);
-int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, hipStream_t s);
+int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
+                    int64_t ws_bytes, int64_t* need, hipStream_t s);
 
 template <int TQ, int TC>
-static int launch(WgradArgs& a, hipStream_t s) {
+static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
     constexpr int KWAVES = 4 / (TQ * TC);
     constexpr int KSUBW = (TQ * TC == 1) ? 1 : 2;
     constexpr int BKP = 32 * KWAVES * KSUBW;
     const aau_conv_desc& d = a.d;
     const int T = d.KH * d.KW;
-    const int64_t tiles = (int64_t)((d.Cout + 48 * TQ - 1) / (48 * TQ)) * ((d.Cin + 48 * TC - 1) / (48 * TC)) * T;
-    // Split-K: each split ends with a tile of fp32 atomics (memory side, ~1.3 TB/s chip-wide, slower still when
-    // many workgroups hit the same few rows), so the split count is a trade against occupancy.  Measured per
-    // shape on one device: 1x1 / 2x2 problems (K-steps are cheap, atomics dominate: -50 % time going from 2048
-    // to 512 workgroups, 256 when the whole matrix is one or two tiles); dilated 3x3 keeps 2048.
+    const int ntq = (d.Cout + 48 * TQ - 1) / (48 * TQ), ntc = (d.Cin + 48 * TC - 1) / (48 * TC);
+    const int64_t tiles = (int64_t)ntq * ntc * T;
+    // Split-K: each split ends with a tile of partial sums.  With fp32 atomics (memory side, ~1.3 TB/s chip-wide,
+    // slower still when many workgroups hit the same few rows) the split count is a trade against occupancy,
+    // measured per shape on one device: 1x1 / 2x2 problems -50 % time going from 2048 to 512 workgroups (256 when
+    // the whole matrix is one or two tiles); dilated 3x3 keeps 2048.
     int64_t tgt = T >= 9 ? 2048 : (T == 1 && tiles <= 8 ? 256 : 512);
     if (const char* e = getenv("AAU_WG_TARGET")) tgt = atoi(e);   // experiment
     int64_t want = (tgt + tiles - 1) / tiles;
@@ -261,34 +380,72 @@ static int launch(WgradArgs& a, hipStream_t s) {
     a.nsplit = (int)nsplit;
     const int64_t grid = tiles * nsplit;
     if (grid > 0x7fffffff) { set_error("aau_conv_wgrad: grid too large"); return AAU_E_INVALID; }
+    const int64_t bytes = grid * (9 * 256 * 4) * (int64_t)sizeof(float);
+    if (need) { *need = bytes; return AAU_OK; }
+    if (ws && ws_bytes < bytes) {
+        set_error("aau_conv_wgrad: workspace of %lld B, need %lld B (aau_conv_wgrad_ws_bytes)", (long long)ws_bytes, (long long)bytes);
+        return AAU_E_INVALID;
+    }
+    a.ws = ws;
     hipLaunchKernelGGL((wgrad_kernel<TQ, TC>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    return check_launch("aau_conv_wgrad");
+    if (!ws) return check_launch("aau_conv_wgrad");
+    WRedArgs r;
+    r.ws = ws; r.dw = a.dw;
+    r.nsplit = a.nsplit; r.NV = 9; r.sub = TQ * TC; r.kwaves = KWAVES;
+    r.TQ = TQ; r.TC = TC; r.ntc = ntc; r.T = T; r.Cout = d.Cout; r.Cin = d.Cin;
+    r.nslots = tiles * 9 * (TQ * TC) * 64;
+    return wg_reduce_launch(0, r, s);
 }
 
 }  // namespace aau
 
-extern "C" int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz,
-                              float* dw, void* stream) {
+static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
+                          int64_t ws_bytes, int64_t* need, void* stream) {
     using namespace aau;
-    AAU_REQUIRE(d && src && dz && dw, "aau_conv_wgrad: null pointer");
+    AAU_REQUIRE(d, "aau_conv_wgrad: null descriptor");
     AAU_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0,
                 "aau_conv_wgrad: Cin=%d / Cout=%d must be positive multiples of 8", d->Cin, d->Cout);
     AAU_REQUIRE(d->src_pitch % 8 == 0 && d->dst_pitch % 8 == 0, "aau_conv_wgrad: pitches must be multiples of 8");
     AAU_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH * d->KW <= 16, "aau_conv_wgrad: taps %dx%d", d->KH, d->KW);
     AAU_REQUIRE((int64_t)d->N * d->H * d->W < 0x7fffffff && (int64_t)d->N * d->Ho * d->Wo < 0x7fffffff,
                 "aau_conv_wgrad: pixel count overflows int32");
-    AAU_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dz & 15) == 0, "aau_conv_wgrad: 16-byte alignment");
+    if (!need) {
+        AAU_REQUIRE(src && dz && dw, "aau_conv_wgrad: null pointer");
+        AAU_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dz & 15) == 0 && ((uintptr_t)ws & 15) == 0,
+                    "aau_conv_wgrad: 16-byte alignment");
+    }
     WgradArgs a;
     a.d = *d;
-    a.src = src; a.dz = dz; a.dw = dw;
+    a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
     a.M = d->N * d->Ho * d->Wo;
     a.linear = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo);
+    if (wgrad3x3_applicable(d)) {
+        if (need) return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream);
+        const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
+        ProfScope prof(1, flops, (hipStream_t)stream);
+        return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream);
+    }
+    const bool q2 = d->Cout > 48, c2 = d->Cin > 48;
+    if (need) {
+        if (q2 && c2) return launch<2, 2>(a, ws, ws_bytes, need, (hipStream_t)stream);
+        if (q2) return launch<2, 1>(a, ws, ws_bytes, need, (hipStream_t)stream);
+        if (c2) return launch<1, 2>(a, ws, ws_bytes, need, (hipStream_t)stream);
+        return launch<1, 1>(a, ws, ws_bytes, need, (hipStream_t)stream);
+    }
     const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
     ProfScope prof(1, flops, (hipStream_t)stream);
-    if (wgrad3x3_applicable(d)) return wgrad3x3_launch(d, src, dz, dw, (hipStream_t)stream);
-    const bool q2 = d->Cout > 48, c2 = d->Cin > 48;
-    if (q2 && c2) return launch<2, 2>(a, (hipStream_t)stream);
-    if (q2) return launch<2, 1>(a, (hipStream_t)stream);
-    if (c2) return launch<1, 2>(a, (hipStream_t)stream);
-    return launch<1, 1>(a, (hipStream_t)stream);
+    if (q2 && c2) return launch<2, 2>(a, ws, ws_bytes, nullptr, (hipStream_t)stream);
+    if (q2) return launch<2, 1>(a, ws, ws_bytes, nullptr, (hipStream_t)stream);
+    if (c2) return launch<1, 2>(a, ws, ws_bytes, nullptr, (hipStream_t)stream);
+    return launch<1, 1>(a, ws, ws_bytes, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
+                              int64_t ws_bytes, void* stream) {
+    return wgrad_dispatch(d, src, dz, dw, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes) {
+    AAU_REQUIRE(bytes, "aau_conv_wgrad_ws_bytes: null pointer");
+    return wgrad_dispatch(d, nullptr, nullptr, nullptr, nullptr, 0, bytes, nullptr);
 }

@@ -35,6 +35,7 @@ struct W3Args {
     const unsigned short* src;   // x   [N][H][W] pitch src_pitch, Cin channels
     const unsigned short* dz;    // dz  [N][H][W] pitch dst_pitch, Cout channels
     float* dw;
+    float* ws;                   // split-K slabs [workgroup][QT*7 acc tiles][256 threads][4] (null: fp32 atomics)
     unsigned src_bytes, dz_bytes;
     int npatch;                  // N * (H/8) * (W/16)
     int patches_per_block, nsplit;
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     const int q0 = tq * BQ, c0 = tc * 48;
     const int p_begin = split * a.patches_per_block;
     const int p_end = min(a.npatch, p_begin + a.patches_per_block);
-    if (p_begin >= p_end) return;
+    if (p_begin >= p_end) {   // never taken with the host's split sizes, but a slab must not stay unwritten
+        if (a.ws)
+            for (int v = 0; v < QT * 7; ++v) *(f32x4*)(a.ws + ((int64_t)blockIdx.x * QT * 7 * 256 + v * 256 + threadIdx.x) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
 
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
@@ -198,6 +203,16 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     }
 
     // acc[i][n][r] = D[q = q0 + i*16 + 4*g16 + r][tap, c = c0 + j*16 + li]
+    if (a.ws) {   // split-K partial in register layout (see wgrad.hip, wg_reduce_kernel<1>)
+        float* slab = a.ws + (int64_t)blockIdx.x * (QT * 7 * 256 * 4);
+#pragma unroll
+        for (int n = 0; n < 7; ++n) {
+            if (n >= nct) continue;
+#pragma unroll
+            for (int i = 0; i < QT; ++i) *(f32x4*)(slab + ((i * 7 + n) * 256 + tid) * 4) = acc[i][n];
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 7; ++n) {
         if (n >= nct) continue;
@@ -220,7 +235,7 @@ bool wgrad3x3_applicable(const aau_conv_desc* d) {
 }
 
 template <int QT, int PR>
-static int launch_w3(W3Args& a, const aau_conv_desc* d, int64_t npix, hipStream_t s) {
+static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
     constexpr int BQ = QT * 16;
     a.tiles_x = d->W / 16;
     a.tiles_y = d->H / PR;
@@ -240,14 +255,28 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, int64_t npix, hipStream_
     a.nsplit = (int)((a.npatch + a.patches_per_block - 1) / a.patches_per_block);
     const int64_t grid = tiles * a.nsplit;
     if (grid > 0x7fffffff) { set_error("aau_conv_wgrad: grid too large"); return AAU_E_INVALID; }
+    const int64_t bytes = grid * (QT * 7 * 256 * 4) * (int64_t)sizeof(float);
+    if (need) { *need = bytes; return AAU_OK; }
+    if (ws && ws_bytes < bytes) {
+        set_error("aau_conv_wgrad: workspace of %lld B, need %lld B (aau_conv_wgrad_ws_bytes)", (long long)ws_bytes, (long long)bytes);
+        return AAU_E_INVALID;
+    }
+    a.ws = ws;
     hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    return check_launch("aau_conv_wgrad(3x3)");
+    if (!ws) return check_launch("aau_conv_wgrad(3x3)");
+    WRedArgs r;
+    r.ws = ws; r.dw = a.dw;
+    r.nsplit = a.nsplit; r.NV = QT * 7; r.sub = 1; r.kwaves = 1;
+    r.TQ = 1; r.TC = 1; r.ntc = (d->Cin + 47) / 48; r.T = 9; r.Cout = d->Cout; r.Cin = d->Cin;
+    r.nslots = tiles * (QT * 7) * 256;
+    return wg_reduce_launch(1, r, s);
 }
 
-int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, hipStream_t s) {
+int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
+                    int64_t ws_bytes, int64_t* need, hipStream_t s) {
     W3Args a;
     a.d = *d;
-    a.src = src; a.dz = dz; a.dw = dw;
+    a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
     const int64_t npix = (int64_t)d->N * d->H * d->W;
     const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin) * 2, zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
     if (sb >= 0x7fffffff || zb >= 0x7fffffff) { set_error("aau_conv_wgrad: tensors must stay below 2 GiB"); return AAU_E_INVALID; }
@@ -255,9 +284,9 @@ int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16*
     a.dz_bytes = (unsigned)zb;
     // The 96-channel variant halves the LDS reads per FLOP but needs 200 VGPRs (1 wave per SIMD): measured
     // 1.7-1.9x SLOWER than <3, 8> at 2 waves per SIMD on the same device, so it stays opt-in (experiments).
-    if (d->Cout > 48 && getenv("AAU_W3_WIDE")) return launch_w3<6, 4>(a, d, npix, s);
-    if (getenv("AAU_W3_PR4")) return launch_w3<3, 4>(a, d, npix, s);   // experiment: 4 workgroups per CU
-    return launch_w3<3, 8>(a, d, npix, s);
+    if (d->Cout > 48 && getenv("AAU_W3_WIDE")) return launch_w3<6, 4>(a, d, ws, ws_bytes, need, s);
+    if (getenv("AAU_W3_PR4")) return launch_w3<3, 4>(a, d, ws, ws_bytes, need, s);   // experiment: 4 workgroups per CU
+    return launch_w3<3, 8>(a, d, ws, ws_bytes, need, s);
 }
 
 }  // namespace aau

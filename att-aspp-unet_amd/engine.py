@@ -50,6 +50,7 @@ class _Rec:
         self.keep = []
         self.side = None        # torch.cuda.Stream, created on first use
         self.uses_side = False
+        self.wg_ops = []        # (op index, workspace bytes) of the weight-gradient launches
 
     def add(self, name, *args, side=False):
         f = _abi.fn(name)
@@ -65,6 +66,22 @@ class _Rec:
                 conv.append(a)
         self.ops.append((f, tuple(conv), name, 1 if side else 0))
         self.uses_side |= side
+
+    def add_wgrad(self, desc, src, dz, dw, side=False):
+        """aau_conv_wgrad with the shared split-K workspace, which is sized and patched in by ``bind_wgrad_ws``."""
+        self.add("aau_conv_wgrad", desc, src, dz, dw, None, 0, side=side)
+        self.wg_ops.append((len(self.ops) - 1, ops.conv_wgrad_ws_bytes(desc)))
+
+    def bind_wgrad_ws(self, device):
+        import os
+        if not self.wg_ops or os.environ.get("AAU_WGRAD_ATOMIC", "0") == "1":   # experiment: fp32-atomic split-K
+            return
+        nbytes = max(n for _, n in self.wg_ops)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        self.keep.append(ws)
+        for i, _ in self.wg_ops:
+            f, a, name, sid = self.ops[i]
+            self.ops[i] = (f, a[:4] + (ws.data_ptr(), nbytes), name, sid)
 
     def callback(self, fn: Callable[[], None]):
         self.ops.append((None, fn, "callback", 0))
@@ -274,6 +291,7 @@ class Plan:
         self.bwd_blocks = []   # per forward block: list of (name, args) recorded later in reverse
         self.bucket_hooks = {}  # block index -> callback fired after that block's backward
         self._build()
+        self.bwd.bind_wgrad_ws(self.dev)
 
     # ---- small helpers ----
     def new(self, *shape, dtype=BF16):
@@ -353,7 +371,7 @@ class Plan:
             b.add("aau_conv1_wgrad", r["src"], dz, cv.dw, N, H, W, cv.O, side=ov)
             return dz
         dwd = ops.conv_desc(N, H, W, cv.I, r["sp"], H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil)
-        b.add("aau_conv_wgrad", dwd, r["src"], dz, cv.dw, side=ov)
+        b.add_wgrad(dwd, r["src"], dz, cv.dw, side=ov)
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate)
@@ -512,10 +530,8 @@ class Plan:
                 ov = eng.overlap_wgrad
                 if ov:
                     b.fork()
-                b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], dzg, wg.dw,
-                      side=ov)
-                b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], dzx,
-                      wx.dw, side=ov)
+                b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], dzg, wg.dw, side=ov)
+                b.add_wgrad(ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], dzx, wx.dw, side=ov)
                 b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, 2 * Co, Cpad=wg.cpad_d,
                                                       accumulate=1), dzg, wg.pk_d, dcat[:, Co:], None, None, None,
                       None)
@@ -527,8 +543,8 @@ class Plan:
             ov = eng.overlap_wgrad
             if ov:
                 b.fork()        # dcat[:, Co:] is final (gate data-gradient accumulated above)
-            b.add("aau_conv_wgrad", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1),
-                  dcat[:, Co:], gsrc, up.dw, side=ov)
+            b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1), dcat[:, Co:], gsrc, up.dw,
+                        side=ov)
             dg_in = self.new(B * hi * wi, gc)
             b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1, up.cpad_d),
                   dcat[:, Co:], up.pk_d, dg_in, None, None, None, None)

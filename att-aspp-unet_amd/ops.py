@@ -52,8 +52,16 @@ def conv_igemm(desc: ConvDesc, src, wpk, dst, bias=None, scale=None, shift=None,
                                _p(stats), _stream()), "aau_conv_igemm")
 
 
-def conv_wgrad(desc: ConvDesc, src, dz, dw):
-    check(fn("aau_conv_wgrad")(C.byref(desc), _p(src), _p(dz), _p(dw), _stream()), "aau_conv_wgrad")
+def conv_wgrad_ws_bytes(desc: ConvDesc) -> int:
+    n = C.c_int64(0)
+    check(fn("aau_conv_wgrad_ws_bytes")(C.byref(desc), C.byref(n)), "aau_conv_wgrad_ws_bytes")
+    return int(n.value)
+
+
+def conv_wgrad(desc: ConvDesc, src, dz, dw, ws=None):
+    """ws: fp32 scratch of >= conv_wgrad_ws_bytes(desc) bytes (deterministic split-K) or None (fp32 atomics)."""
+    nb = 0 if ws is None else ws.numel() * ws.element_size()
+    check(fn("aau_conv_wgrad")(C.byref(desc), _p(src), _p(dz), _p(dw), _p(ws), nb, _stream()), "aau_conv_wgrad")
 
 
 def conv1_fwd(x, w, z, stats, N, H, W, Cc):

@@ -88,13 +88,18 @@ int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    float* stats, void* stream);
 
 /* Weight-gradient of the same convolutions (ATen convolution_backward, weight part):   */
-/* dw[q][t][c] += sum_m dz[m][q] * src[gather(m,t)][c]   (fp32 atomics; caller zeroes)   */
+/* dw[q][t][c] += sum_m dz[m][q] * src[gather(m,t)][c]   (the caller zeroes dw)         */
 /* d->Cout = channels of dz (pitch d->dst_pitch), d->Cin = channels of src.             */
 /* dw is [Cout][KH*KW][Cin] fp32 dense.  ConvTranspose2d(2,2) uses the same entry with    */
 /* the roles swapped by the caller: dz := the layer input g (q = its Cin), src := the      */
 /* output gradient gathered with stride 2 / 2x2 taps (c = Cout), giving [Cin][4][Cout].    */
+/* The pixel reduction is split over workgroups.  With a workspace `ws` (16-byte aligned, */
+/* at least aau_conv_wgrad_ws_bytes(d) bytes, contents don't care) every workgroup stores */
+/* its partial tile and a second launch sums them in a fixed order: bitwise reproducible  */
+/* and faster (no atomic tail).  ws == NULL: partial tiles are added with fp32 atomics.   */
 int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz,
-                   float* dw, void* stream);
+                   float* dw, float* ws, int64_t ws_bytes, void* stream);
+int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes);
 
 /* ---- first layer: Conv2d(1, C, 3, pad 1) on fp32 input (pipeline:113 d1[0]) --------- */
 int aau_conv1_fwd(const float* x, const float* w /*[C][9]*/, aau_bf16* z, float* stats,

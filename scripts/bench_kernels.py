@@ -16,7 +16,22 @@ LAYERS = [  # name, H(=W), Cin, Cout, k, dil
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="")
 ap.add_argument("--modes", default="fwd,dgrad,wgrad")
+ap.add_argument("--atomic", action="store_true", help="fp32-atomic split-K in the weight gradients (no workspace)")
 a = ap.parse_args()
+
+
+_ws = None
+
+
+def wgrad(d, src, dz, dw):
+    """aau_conv_wgrad with a shared deterministic split-K workspace (as the engine runs it)."""
+    global _ws
+    if a.atomic:
+        return ops.conv_wgrad(d, src, dz, dw)
+    n = ops.conv_wgrad_ws_bytes(d) // 4
+    if _ws is None or _ws.numel() < n:
+        _ws = torch.empty(n, device="cuda")
+    ops.conv_wgrad(d, src, dz, dw, _ws)
 
 
 def timeit(fn, n=10):
@@ -62,7 +77,7 @@ for name, H, Ci, Co, k, dil in LAYERS:
     if "wgrad" in tot:
         dw = torch.zeros(Co, k * k, Ci, device="cuda")
         d = ops.conv_desc(B, H, H, Ci, Ci, H, H, Co, Co, k, k, 1, pad, dil)
-        t = timeit(lambda: ops.conv_wgrad(d, x, dz, dw))
+        t = timeit(lambda: wgrad(d, x, dz, dw))
         tot["wgrad"] += t
         line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     print(line, flush=True)
@@ -98,7 +113,7 @@ for name, hi, gc, Co in UPS:
     if "wgrad" in tot:
         dw = torch.zeros(gc, 4, Co, device="cuda")
         d = ops.conv_desc(B, ho, ho, Co, 2 * Co, hi, hi, gc, gc, 2, 2, 2, 0, 1)
-        t = timeit(lambda: ops.conv_wgrad(d, cat[:, Co:], g, dw))
+        t = timeit(lambda: wgrad(d, cat[:, Co:], g, dw))
         tot["wgrad"] += t
         line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     print(line, flush=True)
@@ -133,7 +148,7 @@ for name, ho, Co in GATES:
         dw = torch.zeros(Fi, 1, Co, device="cuda")
         d1 = ops.conv_desc(B, ho, ho, Co, 2 * Co, ho, ho, Fi, Fi)
         d2 = ops.conv_desc(B, ho, ho, Co, Co, ho, ho, Fi, Fi)
-        t = timeit(lambda: (ops.conv_wgrad(d1, cat[:, Co:], zg, dw), ops.conv_wgrad(d2, skip, zx, dw)))
+        t = timeit(lambda: (wgrad(d1, cat[:, Co:], zg, dw), wgrad(d2, skip, zx, dw)))
         tot["wgrad"] += t
         line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     print(line, flush=True)

@@ -211,8 +211,18 @@ WGRAD_CASES = [
 ]
 
 
+def _wgrad_ws(ops, d, mode):
+    """mode 'atomic': fp32-atomic split-K; 'slab': deterministic split-K through a NaN-poisoned workspace."""
+    if mode == "atomic":
+        return None
+    n = ops.conv_wgrad_ws_bytes(d)
+    assert n > 0 and n % 16 == 0
+    return torch.full((n // 4,), float("nan"), device="cuda")
+
+
+@pytest.mark.parametrize("mode", ["slab", "atomic"])
 @pytest.mark.parametrize("case", WGRAD_CASES)
-def test_wgrad(ops, case):
+def test_wgrad(ops, case, mode):
     N, H, W, Cin, Cout, k, dil = case
     g = torch.Generator().manual_seed(sum(case) + 1)
     x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
@@ -220,13 +230,24 @@ def test_wgrad(ops, case):
     ref = R.conv_wgrad(x, dy, (Cout, Cin, k, k), dil)  # OIHW
     d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, dil * (k // 2), dil)
     dw = torch.zeros(Cout, k * k, Cin, device="cuda")
-    ops.conv_wgrad(d, dev(x.to(torch.bfloat16)), dev(dy.to(torch.bfloat16)), dw)
+    ws = _wgrad_ws(ops, d, mode)
+    xd, dyd = dev(x.to(torch.bfloat16)), dev(dy.to(torch.bfloat16))
+    ops.conv_wgrad(d, xd, dyd, dw, ws)
     torch.cuda.synchronize()
     got = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 2e-3
+    if mode == "slab":
+        # accumulates into dw (like the atomic form) and is bitwise reproducible
+        dw2 = dw.clone()
+        ops.conv_wgrad(d, xd, dyd, dw2, ws)
+        dw3 = torch.zeros_like(dw)
+        ops.conv_wgrad(d, xd, dyd, dw3, ws)
+        assert torch.equal(dw3, dw)
+        assert rel_err(dw2.cpu(), 2 * dw.cpu()) < 1e-6
 
 
-def test_wgrad_convT(ops):
+@pytest.mark.parametrize("mode", ["slab", "atomic"])
+def test_wgrad_convT(ops, mode):
     N, H, W, Ci, Co = 2, 8, 12, 64, 32
     g = torch.Generator().manual_seed(29)
     x = R.bf16_round(torch.randn(N, H, W, Ci, generator=g))
@@ -235,7 +256,7 @@ def test_wgrad_convT(ops):
     ref = R.convT_wgrad(x, dy, w)  # [Ci][Co][2][2]
     d = ops.conv_desc(N, 2 * H, 2 * W, Co, Co, H, W, Ci, Ci, 2, 2, 2, 0, 1)
     dw = torch.zeros(Ci, 4, Co, device="cuda")
-    ops.conv_wgrad(d, dev(dy.to(torch.bfloat16)), dev(x.to(torch.bfloat16)), dw)
+    ops.conv_wgrad(d, dev(dy.to(torch.bfloat16)), dev(x.to(torch.bfloat16)), dw, _wgrad_ws(ops, d, mode))
     torch.cuda.synchronize()
     got = dw.cpu().reshape(Ci, 2, 2, Co).permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 2e-3
