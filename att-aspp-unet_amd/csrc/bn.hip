@@ -336,6 +336,135 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     }
 }
 
+// Last step of the backward pass: BatchNorm+ReLU backward of d1[0] fused with the weight gradient of its
+// Conv2d(1, C, 3, pad 1) (pipeline:113).  The first layer has no input gradient, so dz is consumed here and never
+// written (-2 tensor passes of the largest activation).  dz is rounded to bf16 exactly as the stored form would be.
+// ws: [AAU_STAT_REPLICAS][C*9] fp32 partial sums (zeroed by the caller, folded into dw afterwards).
+__global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned short* z, int zp, const float* gamma,
+                                                                 const float* mean, const float* invstd,
+                                                                 const float* red, float* dgamma, float* dbeta, int M,
+                                                                 int C, const unsigned short* dy, int dyp,
+                                                                 const float* scale, const float* shift,
+                                                                 const float* x, int H, int W, float* ws, int ppb) {
+    extern __shared__ float sm[];   // [2][C] replica sums, then [C*9] workgroup accumulators
+    float* sacc = sm + 2 * C;
+    for (int cc = threadIdx.x; cc < C; cc += 256) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
+            a += red[(size_t)r * 2 * C + cc];
+            b += red[(size_t)r * 2 * C + C + cc];
+        }
+        sm[cc] = a;
+        sm[C + cc] = b;
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[cc] += a;
+            if (dgamma) dgamma[cc] += b;
+        }
+    }
+    for (int i = threadIdx.x; i < C * 9; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    // A thread owns FOUR channels (not the eight of the other BN kernels): 36 accumulators + 20 constants keep
+    // it under 96 VGPRs, i.e. 5 waves per SIMD -- at 8 channels (184 VGPRs, 2 waves) the loop was latency bound
+    // and slower than the two unfused passes.
+    const int CG4 = C >> 2, PL4 = 256 / CG4, T4 = CG4 * PL4;
+    const int tid = threadIdx.x;
+    const int cg = tid % CG4, pl = tid / CG4, c = cg * 4;
+    if (tid < T4) {
+        // dz = k0*(g - k1 - zhat*k2) = ka*g + kb*z + kc  (three folded constants per channel)
+        float ka[4], kb[4], kc[4], sc[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float is = invstd[c + j], mu = mean[c + j];
+            const float k0 = gamma[c + j] * is;
+            const float k1 = sm[c + j] / (float)M, k2 = sm[C + c + j] / (float)M;
+            ka[j] = k0;
+            kb[j] = -k0 * k2 * is;
+            kc[j] = -k0 * k1 + k0 * k2 * is * mu;
+            sc[j] = scale[c + j];
+            sh[j] = shift[c + j];
+        }
+        // accumulators as float pairs: the compiler emits v_pk_fma_f32 (two taps per instruction)
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        f32x2 acc[4][5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) acc[j][k] = f32x2{0.f, 0.f};
+        const int m0 = blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        // (row, column) of the thread's pixel, advanced incrementally (no division in the loop)
+        int m = m0 + pl;
+        int xx = m % W, row = m / W;            // row = n*H + y
+        int yy = row % H;
+        const int stepx = PL4 % W, stepr = PL4 / W;
+        auto load_px = [&](u32x2& zq, u32x2& gq, f32x2 v[5]) {
+            const float* img = x + (int64_t)(row - yy) * W;
+            zq = *(const u32x2*)(z + (int64_t)m * zp + c);
+            gq = *(const u32x2*)(dy + (int64_t)m * dyp + c);
+            float t[10];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+                    t[ky * 3 + kx] = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) ? img[y2 * W + x2] : 0.f;
+                }
+            t[9] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] = f32x2{t[2 * k], t[2 * k + 1]};
+            // advance to this thread's next pixel
+            m += PL4;
+            xx += stepx;
+            row += stepr;
+            if (xx >= W) { xx -= W; ++row; }
+            yy = row % H;
+        };
+        auto fma_px = [&](const u32x2& zq, const u32x2& gq, const f32x2 v[5]) {
+            const float zz[4] = {__uint_as_float(zq[0] << 16), __uint_as_float(zq[0] & 0xffff0000u),
+                                 __uint_as_float(zq[1] << 16), __uint_as_float(zq[1] & 0xffff0000u)};
+            const float g[4] = {__uint_as_float(gq[0] << 16), __uint_as_float(gq[0] & 0xffff0000u),
+                                __uint_as_float(gq[1] << 16), __uint_as_float(gq[1] & 0xffff0000u)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gm = (zz[j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;
+                const float gv = bf2f(f2bf(ka[j] * gm + kb[j] * zz[j] + kc[j]));
+                const f32x2 g2 = f32x2{gv, gv};
+#pragma unroll
+                for (int k = 0; k < 5; ++k) acc[j][k] = __builtin_elementwise_fma(g2, v[k], acc[j][k]);
+            }
+        };
+        // two pixels per trip: both sets of loads are in flight before the first FMA block
+        while (m + PL4 < m1) {
+            u32x2 za, ga, zb, gb;
+            f32x2 va[5], vb[5];
+            load_px(za, ga, va);
+            load_px(zb, gb, vb);
+            fma_px(za, ga, va);
+            fma_px(zb, gb, vb);
+        }
+        if (m < m1) {
+            u32x2 za, ga;
+            f32x2 va[5];
+            load_px(za, ga, va);
+            fma_px(za, ga, va);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicAdd(&sacc[(c + j) * 9 + k], acc[j][k >> 1][k & 1]);
+    }
+    __syncthreads();
+    float* rep = ws + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * C * 9;
+    for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(rep + i, sacc[i]);
+}
+
+__global__ void fold_conv1_kernel(const float* ws, float* dw, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int r = 0; r < AAU_STAT_REPLICAS; ++r) a += ws[(size_t)r * n + i];
+    dw[i] += a;
+}
+
 // rows per block so that the grid is ~8 workgroups per CU and every thread gets a few iterations
 static inline void rows_split(int64_t M, int PL, int64_t* blocks, int64_t* ppb) {
     int64_t b = (M + (int64_t)PL * 4 - 1) / ((int64_t)PL * 4);
@@ -474,4 +603,26 @@ extern "C" int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, in
                        dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, M, C, dy, dy_pitch, scale, shift,
                        relu, drop_p, drop_seed, ppb);
     return check_launch("aau_bn_bwd_apply");
+}
+
+extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const float* gamma, const float* save_mean,
+                                      const float* save_invstd, const float* red, float* dgamma, float* dbeta, int N,
+                                      int H, int W, int C, const aau_bf16* dy, int dy_pitch, const float* scale,
+                                      const float* shift, const float* x, float* dw, float* ws, void* stream) {
+    AAU_REQUIRE(z && gamma && save_mean && save_invstd && red && dy && scale && shift && x && dw && ws && N > 0 && H > 0 &&
+                    W > 0, "aau_bn_bwd_apply_conv1: bad args");
+    CHK_C("aau_bn_bwd_apply_conv1", C);
+    AAU_REQUIRE(z_pitch % 8 == 0 && dy_pitch % 8 == 0, "aau_bn_bwd_apply_conv1: pitches must be multiples of 8");
+    const int64_t M = (int64_t)N * H * W;
+    AAU_REQUIRE(M < 0x7fffffff, "aau_bn_bwd_apply_conv1: pixel count overflows int32");
+    ProfScope prof(2, 2.0 * M * 9.0 * C, (hipStream_t)stream);
+    int64_t blocks, ppb;
+    AAU_REQUIRE(C <= 1024, "aau_bn_bwd_apply_conv1: C=%d too wide for one workgroup", C);
+    rows_split(M, 256 / (C >> 2), &blocks, &ppb);
+    zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * C * 9, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel, dim3((unsigned)blocks), dim3(256), (2 * C + 9 * C) * sizeof(float),
+                       (hipStream_t)stream, z, z_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, (int)M, C, dy,
+                       dy_pitch, scale, shift, x, H, W, ws, (int)ppb);
+    hipLaunchKernelGGL(fold_conv1_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9);
+    return check_launch("aau_bn_bwd_apply_conv1");
 }

@@ -350,12 +350,18 @@ class Plan:
         cv, bn, w = r["cv"], r["bn"], r["w"]
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
-        dz = self.new(M, cv.O)
         dp_ = self.drop_p if r["drop"] else 0.0
+        fuse1 = cv.kind == "first" and dpool is None and dp_ == 0.0 and not self.eng.no_fuse_conv1
+        dz = None if fuse1 else self.new(M, cv.O)
         if dpool is None:
             # no pooling: the reduce pass only accumulates, the apply pass recomputes the ReLU / dropout mask
             b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"], w["mean"],
                   w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
+            if fuse1:
+                # first layer: no input gradient, so the apply pass feeds the weight gradient directly
+                b.add("aau_bn_bwd_apply_conv1", r["z"], cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
+                      bn.dbeta, N, H, W, cv.O, dy, dyp, w["scale"], w["shift"], r["src"], cv.dw, self.rep_ws)
+                return None
             b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
                   bn.dbeta, M, cv.O, dy, dyp, w["scale"], w["shift"], 1, dp_, self.drop_seed)
         else:
@@ -498,7 +504,7 @@ class Plan:
         b = self.bwd
         mark = self._mark
         dy = self.new(Ms[0], c)
-        rep_ws = self.new(STAT_REPLICAS * (max(Cs) + 8), dtype=F32)   # replica scratch of the column reductions
+        rep_ws = self.rep_ws = self.new(STAT_REPLICAS * (max(Cs) + 8), dtype=F32)   # replica scratch of the column reductions
         b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, rep_ws, Ms[0], c)
         dskip = [None, self.new(Ms[1], Cs[1]), self.new(Ms[2], Cs[2]), self.new(Ms[3], Cs[3])]
         dcat1 = None
@@ -623,6 +629,7 @@ class Engine:
         self.bucket_cb = None   # set by the data-parallel wrapper: name -> callable
         import os
         self.overlap_wgrad = os.environ.get("AAU_OVERLAP_WGRAD", "0") == "1"   # measured null on MI355X (A/B, same device)
+        self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switch
 
     def next_seed(self) -> int:
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF

@@ -117,6 +117,12 @@ def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, C
                                  drop_seed, _stream()), "aau_bn_bwd_apply")
 
 
+def bn_bwd_apply_conv1(z, zp, gamma, smean, sinvstd, red, dgamma, dbeta, N, H, W, Cc, dy, dyp, scale, shift, x, dw, ws):
+    check(fn("aau_bn_bwd_apply_conv1")(_p(z), zp, _p(gamma), _p(smean), _p(sinvstd), _p(red), _p(dgamma), _p(dbeta),
+                                       N, H, W, Cc, _p(dy), dyp, _p(scale), _p(shift), _p(x), _p(dw), _p(ws), _stream()),
+          "aau_bn_bwd_apply_conv1")
+
+
 def gap_fwd(x, xp, pooled, ws, N, HW, Cc):
     check(fn("aau_gap_fwd")(_p(x), xp, _p(pooled), _p(ws), N, HW, Cc, _stream()), "aau_gap_fwd")
 

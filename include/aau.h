@@ -166,6 +166,15 @@ int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
                      const aau_bf16* dy, int dy_pitch, const float* scale, const float* shift,
                      int relu, float drop_p, uint64_t drop_seed, void* stream);
 
+/* First layer (pipeline:113 d1[0]): the apply pass fused with the weight gradient of its   */
+/* Conv2d(1, C, 3, pad 1) -- the layer has no input gradient, so dz is never written.     */
+/* x: the fp32 frame [N][H][W]; dw: [C][9] fp32 (+=); ws: fp32 [32][C*9] scratch.          */
+int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const float* gamma, const float* save_mean,
+                           const float* save_invstd, const float* red, float* dgamma, float* dbeta,
+                           int N, int H, int W, int C, const aau_bf16* dy, int dy_pitch,
+                           const float* scale, const float* shift, const float* x, float* dw,
+                           float* ws, void* stream);
+
 /* ---- ASPP image-pool branch (pipeline:75-77,82) -------------------------------------- */
 /* ws: caller-provided fp32 [N*C] workspace (zeroed by the call)                        */
 int aau_gap_fwd(const aau_bf16* x, int x_pitch, aau_bf16* pooled, float* ws, int N, int HW, int C, void* stream);

@@ -137,6 +137,42 @@ def test_maxpool_and_bn_backward_with_pool_routing(ops, C):
     assert torch.equal(dz2.cpu(), dz.cpu())
 
 
+@pytest.mark.parametrize("C", [48, 8, 104])
+def test_first_layer_fused_bn_backward_and_weight_gradient(ops, C):
+    """aau_bn_bwd_apply_conv1 == aau_bn_bwd_apply (dz stored in bf16) followed by aau_conv1_wgrad, and both match
+    the CPU weight gradient of Conv2d(1, C, 3, pad 1) (pipeline:113)."""
+    N, H, W = 2, 24, 40
+    g = torch.Generator().manual_seed(100 + C)
+    x = torch.randn(N, H, W, generator=g)
+    z = R.bf16_round(torch.randn(N, H, W, C, generator=g))
+    gy = R.bf16_round(torch.randn(N, H, W, C, generator=g))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    flat = z.reshape(-1, C)
+    mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    zd, gyd, xd = dev(bf(z)), dev(bf(gy)), dev(x)
+    scale, shift = dev(gamma * invstd), dev(beta - mean * gamma * invstd)
+    red = zeros(ops.STAT_REPLICAS, 2, C)
+    ops.bn_bwd_reduce(zd, C, gyd, C, None, 0, None, C, scale, shift, dev(mean), dev(invstd), red, N, H, W, C, relu=1)
+    # unfused pair
+    dz = zeros(N, H, W, C, dtype=torch.bfloat16)
+    dg0, db0, dw0 = zeros(C), zeros(C), zeros(C, 9)
+    ops.bn_bwd_apply(zd, C, dz, C, dev(gamma), dev(mean), dev(invstd), red, dg0, db0, N * H * W, C, dy=gyd, dyp=C,
+                     scale=scale, shift=shift, relu=1)
+    ops.conv1_wgrad(xd, dz, dw0, N, H, W, C)
+    # fused
+    dg1, db1, dw1 = zeros(C), zeros(C), zeros(C, 9)
+    ws = torch.full((ops.STAT_REPLICAS * C * 9,), float("nan"), device="cuda")
+    ops.bn_bwd_apply_conv1(zd, C, dev(gamma), dev(mean), dev(invstd), red, dg1, db1, N, H, W, C, gyd, C, scale, shift,
+                           xd, dw1, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    assert rel_err(dw1.cpu(), dw0.cpu()) < 1e-4               # same bf16-rounded dz, different summation order
+    # CPU: weight gradient from the stored dz
+    ref = torch.nn.grad.conv2d_weight(x[:, None], (C, 1, 3, 3), dz.float().cpu().permute(0, 3, 1, 2), padding=1)
+    assert rel_err(dw1.cpu().reshape(C, 1, 3, 3), ref) < 1e-4
+
+
 def test_dropout_mask_is_consistent_between_forward_and_backward(ops):
     M, C, p = 4096, 64, 0.1
     z = torch.ones(M, C, dtype=torch.bfloat16, device="cuda")
