@@ -69,7 +69,7 @@ _SIGS = {
     "aau_gate_apply": [P, I, P, P, P, P, P, I, L, I, P],
     "aau_gate_bwd1": [P, I, P, I, P, P, P, P, P, I, P, P, L, I, P],
     "aau_gate_bwd2": [P] * 23 + [L, I, P],
-    "aau_gate_bwd3": [P] * 17 + [L, I, P],
+    "aau_gate_bwd3": [P] * 19 + [L, I, P],
     "aau_outconv_fwd": [P, I, P, P, P, L, I, P],
     "aau_outconv_bwd": [P, I, P, P, P, I, P, P, P, L, I, P],
     "aau_colsum": [P, I, P, P, L, I, P],

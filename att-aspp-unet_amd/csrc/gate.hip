@@ -4,6 +4,7 @@
 //   gate_psi   : s = relu(bn(zg)+bn(zx)); psi_pre = <wpsi, s>; sum / sumsq of psi_pre
 //   gate_apply : alpha = sigmoid(bn1(psi_pre)); out = x * alpha (written into the concat slot)
 // and the mirrored three backward passes.
+#include <stdlib.h>
 #include "common.h"
 
 namespace aau {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void gate_bwd2_kernel(
     const float* dq, const float* psi_pre, const float* red1, const float* gamma1, const float* mean1,
     const float* invstd1, const unsigned short* zg, const unsigned short* zx, const float* sg, const float* hg,
     const float* sx, const float* hx, const float* mean_g, const float* invstd_g, const float* mean_x,
-    const float* invstd_x, const float* wpsi, unsigned short* ds, float* dwpsi, float* redg, float* redx,
+    const float* invstd_x, const float* wpsi, unsigned short* ds, float* dwpsi_rep, float* redg, float* redx,
     float* dgamma1, float* dbeta1, int64_t M, int F, int64_t ppb) {
     __shared__ float sred[256 * 8];
     const CGMap3 mp(F);
@@ -192,12 +193,12 @@ __global__ __launch_bounds__(256) void gate_bwd2_kernel(
         ldf8g(sg + c, v_sg); ldf8g(hg + c, v_hg); ldf8g(sx + c, v_sx); ldf8g(hx + c, v_hx); ldf8g(wpsi + c, v_w);
         ldf8g(mean_g + c, v_mg); ldf8g(invstd_g + c, v_ig); ldf8g(mean_x + c, v_mx); ldf8g(invstd_x + c, v_ix);
         const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
-        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
-            const float ph = (psi_pre[m] - mu1) * is1;
-            const float dp = k0 * (dq[m] - k1 - ph * k2);
+        auto body = [&](int64_t m, float pp, float dqv, const u32x4& qa, const u32x4& qb) {
+            const float ph = (pp - mu1) * is1;
+            const float dp = k0 * (dqv - k1 - ph * k2);
             float a[8], b[8], o[8];
-            unpack8(*(const u32x4*)(zg + m * F + c), a);
-            unpack8(*(const u32x4*)(zx + m * F + c), b);
+            unpack8(qa, a);
+            unpack8(qb, b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float s = a[j] * v_sg[j] + v_hg[j] + b[j] * v_sx[j] + v_hx[j];
@@ -210,13 +211,24 @@ __global__ __launch_bounds__(256) void gate_bwd2_kernel(
                 o[j] = d;
             }
             *(u32x4*)(ds + m * F + c) = pack8(o);
+        };
+        // the loop is latency bound: keep the loads of two pixels in flight per thread
+        int64_t m = m0 + pl;
+        for (; m + mp.PL < m1; m += 2 * mp.PL) {
+            const int64_t mb = m + mp.PL;
+            const float p0 = psi_pre[m], d0 = dq[m], p1 = psi_pre[mb], d1 = dq[mb];
+            const u32x4 a0 = *(const u32x4*)(zg + m * F + c), b0 = *(const u32x4*)(zx + m * F + c);
+            const u32x4 a1 = *(const u32x4*)(zg + mb * F + c), b1 = *(const u32x4*)(zx + mb * F + c);
+            body(m, p0, d0, a0, b0);
+            body(mb, p1, d1, a1, b1);
         }
+        if (m < m1) body(m, psi_pre[m], dq[m], *(const u32x4*)(zg + m * F + c), *(const u32x4*)(zx + m * F + c));
     }
     const int rep = blockIdx.x % AAU_STAT_REPLICAS;
     block_sum8c(a_w, sred, mp, tid);
     if (tid < mp.CG) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(dwpsi + c + j, a_w[j]);
+        for (int j = 0; j < 8; ++j) atomicAdd(dwpsi_rep + (size_t)rep * F + c + j, a_w[j]);   // replicas: one shared row serialises the adds
     }
     block_sum8c(a_s, sred, mp, tid);
     if (tid < mp.CG) {
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(256) void gate_bwd3_kernel(
     const unsigned short* ds, const unsigned short* zg, const unsigned short* zx, const float* gamma_g,
     const float* mean_g, const float* invstd_g, const float* redg, const float* gamma_x, const float* mean_x,
     const float* invstd_x, const float* redx, unsigned short* dzg, unsigned short* dzx, float* dgamma_g,
-    float* dbeta_g, float* dgamma_x, float* dbeta_x, int64_t M, int F) {
+    float* dbeta_g, float* dgamma_x, float* dbeta_x, const float* dwpsi_rep, float* dwpsi, int64_t M, int F) {
     extern __shared__ float sm[];  // [6][F]
     float* g0 = sm; float* g1 = sm + F; float* g2 = sm + 2 * F;
     float* x0 = sm + 3 * F; float* x1 = sm + 4 * F; float* x2 = sm + 5 * F;
@@ -259,6 +271,11 @@ __global__ __launch_bounds__(256) void gate_bwd3_kernel(
             if (dgamma_g) dgamma_g[c] += b;
             if (dbeta_x) dbeta_x[c] += a2;
             if (dgamma_x) dgamma_x[c] += b2;
+            if (dwpsi) {
+                float w = 0.f;
+                for (int r = 0; r < AAU_STAT_REPLICAS; ++r) w += dwpsi_rep[(size_t)r * F + c];
+                dwpsi[c] += w;
+            }
         }
     }
     __syncthreads();
@@ -302,7 +319,7 @@ extern "C" int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float*
     CHK_F("aau_gate_psi", F);
     ProfScope prof(2, 2.0 * M * F, (hipStream_t)stream);
     const CGMap3 mp(F);
-    int64_t b = (M + (int64_t)mp.PL * 8 - 1) / ((int64_t)mp.PL * 8);
+    int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
     const int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
@@ -333,7 +350,7 @@ extern "C" int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf1
     AAU_REQUIRE(dout_pitch % 8 == 0 && x_pitch % 8 == 0 && dx_pitch % 8 == 0, "aau_gate_bwd1: pitch");
     ProfScope prof(2, 0, (hipStream_t)stream);
     const CGMap3 mp(C);
-    int64_t b = (M + (int64_t)mp.PL * 8 - 1) / ((int64_t)mp.PL * 8);
+    int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
     const int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
@@ -347,22 +364,25 @@ extern "C" int aau_gate_bwd2(const float* dq, const float* psi_pre, const float*
                              const float* mean1, const float* invstd1, const aau_bf16* zg, const aau_bf16* zx,
                              const float* sg, const float* hg, const float* sx, const float* hx,
                              const float* mean_g, const float* invstd_g, const float* mean_x,
-                             const float* invstd_x, const float* wpsi, aau_bf16* ds, float* dwpsi, float* redg,
+                             const float* invstd_x, const float* wpsi, aau_bf16* ds, float* dwpsi_rep, float* redg,
                              float* redx, float* dgamma1, float* dbeta1, int64_t M, int F, void* stream) {
     AAU_REQUIRE(dq && psi_pre && red1 && gamma1 && mean1 && invstd1 && zg && zx && sg && hg && sx && hx && mean_g &&
-                    invstd_g && mean_x && invstd_x && wpsi && ds && dwpsi && redg && redx && M > 0,
+                    invstd_g && mean_x && invstd_x && wpsi && ds && dwpsi_rep && redg && redx && M > 0,
                 "aau_gate_bwd2: bad args");
     CHK_F("aau_gate_bwd2", F);
     const CGMap3 mp(F);
+    // 16 pixels per thread (two in flight): every workgroup ends with 4 block reductions + replica atomics, so
+    // fewer, longer workgroups win (8: +20-40 %, 4: +60-100 %)
     int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
-    if (b > 2048) b = 2048;
+    if (const char* e = getenv("AAU_GB2_PPT")) b = (M + (int64_t)mp.PL * atoi(e) - 1) / ((int64_t)mp.PL * atoi(e));   // experiment
+    if (b > 4096) b = 4096;
     if (b < 1) b = 1;
     const int64_t ppb = (M + b - 1) / b;
     b = (M + ppb - 1) / ppb;
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(gate_bwd2_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dq, psi_pre, red1,
                        gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x, invstd_x, wpsi, ds,
-                       dwpsi, redg, redx, dgamma1, dbeta1, M, F, ppb);
+                       dwpsi_rep, redg, redx, dgamma1, dbeta1, M, F, ppb);
     return check_launch("aau_gate_bwd2");
 }
 
@@ -370,13 +390,13 @@ extern "C" int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_b
                              const float* mean_g, const float* invstd_g, const float* redg, const float* gamma_x,
                              const float* mean_x, const float* invstd_x, const float* redx, aau_bf16* dzg,
                              aau_bf16* dzx, float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x,
-                             int64_t M, int F, void* stream) {
+                             const float* dwpsi_rep, float* dwpsi, int64_t M, int F, void* stream) {
     AAU_REQUIRE(ds && zg && zx && gamma_g && mean_g && invstd_g && redg && gamma_x && mean_x && invstd_x && redx &&
-                    dzg && dzx && M > 0, "aau_gate_bwd3: bad args");
+                    dzg && dzx && M > 0 && (!dwpsi || dwpsi_rep), "aau_gate_bwd3: bad args");
     CHK_F("aau_gate_bwd3", F);
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(gate_bwd3_kernel, dim3(grid1(M * (F / 8))), dim3(256), 6 * F * sizeof(float),
                        (hipStream_t)stream, ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x,
-                       redx, dzg, dzx, dgamma_g, dbeta_g, dgamma_x, dbeta_x, M, F);
+                       redx, dzg, dzx, dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi_rep, dwpsi, M, F);
     return check_launch("aau_gate_bwd3");
 }

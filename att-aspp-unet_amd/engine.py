@@ -283,7 +283,7 @@ class Plan:
         st = eng.store
         nbn = st.bn_channels + 8
         self.stats_arena = _Arena(STAT_REPLICAS * 2 * nbn, self.dev)
-        self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3, self.dev)
+        self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3 + STAT_REPLICAS * nbn, self.dev)
         self.vec_arena = _Arena(nbn * 8 + 64, self.dev)
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
         self.logits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
@@ -487,7 +487,8 @@ class Plan:
                 f.add("aau_gate_apply", skips[lv], skip_p[lv], psi_pre, w1["scale"], w1["shift"], alpha, cat, 2 * Co,
                       Mo, Co)
                 gate = dict(wg=wg, wx=wx, psi=psi, bg=bg, bx=bx, b1=b1, wgb=wgb, wxb=wxb, w1=w1, zg=zg, zx=zx,
-                            psi_pre=psi_pre, alpha=alpha, Fi=Fi)
+                            psi_pre=psi_pre, alpha=alpha, Fi=Fi,
+                            wrep=self.red_arena.take(STAT_REPLICAS * Fi) if tr else None)
             ya = self.new(Mo, Co)
             ra = self.cbr_fwd(f"{name}.conv.0.block.0", f"{name}.conv.0.block.1", cat, 2 * Co, B, ho, wo, ya, Co)
             yb = self.new(Mo, Co)
@@ -527,11 +528,11 @@ class Plan:
                       w1["invstd"], dskip[lv], Co, dq, red1, Mo, Co)
                 b.add("aau_gate_bwd2", dq, gt["psi_pre"], red1, gt["b1"].gamma, w1["mean"], w1["invstd"], gt["zg"],
                       gt["zx"], wgb["scale"], wgb["shift"], wxb["scale"], wxb["shift"], wgb["mean"], wgb["invstd"],
-                      wxb["mean"], wxb["invstd"], gt["psi"].w, ds, gt["psi"].dw, wgb["red"], wxb["red"],
+                      wxb["mean"], wxb["invstd"], gt["psi"].w, ds, gt["wrep"], wgb["red"], wxb["red"],
                       gt["b1"].dgamma, gt["b1"].dbeta, Mo, Fi)
                 b.add("aau_gate_bwd3", ds, gt["zg"], gt["zx"], gt["bg"].gamma, wgb["mean"], wgb["invstd"], wgb["red"],
                       gt["bx"].gamma, wxb["mean"], wxb["invstd"], wxb["red"], dzg, dzx, gt["bg"].dgamma,
-                      gt["bg"].dbeta, gt["bx"].dgamma, gt["bx"].dbeta, Mo, Fi)
+                      gt["bg"].dbeta, gt["bx"].dgamma, gt["bx"].dbeta, gt["wrep"], gt["psi"].dw, Mo, Fi)
                 wg, wx = gt["wg"], gt["wx"]
                 ov = eng.overlap_wgrad
                 if ov:

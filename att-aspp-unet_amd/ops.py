@@ -151,16 +151,17 @@ def gate_bwd1(dout, dop, x, xp, alpha, psi_pre, mean1, invstd1, dx, dxp, dq, red
 
 
 def gate_bwd2(dq, psi_pre, red1, gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x,
-              invstd_x, wpsi, ds, dwpsi, redg, redx, dgamma1, dbeta1, M, Fi):
+              invstd_x, wpsi, ds, dwpsi_rep, redg, redx, dgamma1, dbeta1, M, Fi):
+    """dwpsi_rep: zeroed fp32 [STAT_REPLICAS][Fi]; gate_bwd3 folds it into the psi weight gradient."""
     args = [dq, psi_pre, red1, gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x,
-            invstd_x, wpsi, ds, dwpsi, redg, redx, dgamma1, dbeta1]
+            invstd_x, wpsi, ds, dwpsi_rep, redg, redx, dgamma1, dbeta1]
     check(fn("aau_gate_bwd2")(*[_p(a) for a in args], M, Fi, _stream()), "aau_gate_bwd2")
 
 
 def gate_bwd3(ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x, redx, dzg, dzx,
-              dgamma_g, dbeta_g, dgamma_x, dbeta_x, M, Fi):
+              dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi_rep, dwpsi, M, Fi):
     args = [ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x, redx, dzg, dzx,
-            dgamma_g, dbeta_g, dgamma_x, dbeta_x]
+            dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi_rep, dwpsi]
     check(fn("aau_gate_bwd3")(*[_p(a) for a in args], M, Fi, _stream()), "aau_gate_bwd3")
 
 

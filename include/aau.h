@@ -200,22 +200,25 @@ int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x
                   const float* invstd1, aau_bf16* dx, int dx_pitch, float* dq, float* red1,
                   int64_t M, int C, void* stream);
 /* backward step 2: dpsi_pre = BN(1) backward of dq; ds[m,f] = dpsi_pre*wpsi[f]*[s>0];      */
-/* writes ds (bf16, masked gradient shared by both branches), dwpsi[f] += sum dpsi_pre*s,   */
+/* writes ds (bf16, masked gradient shared by both branches); dwpsi_rep [REPLICAS][F] +=     */
+/* partial sums of dpsi_pre*s (zeroed by the caller, folded into the weight gradient by     */
+/* step 3: every workgroup adding into ONE 48-float row serialised the launch);              */
 /* redg/redx [REPLICAS][2][F] += (ds, ds*zhat_g) / (ds, ds*zhat_x); dgamma1/dbeta1.         */
 int aau_gate_bwd2(const float* dq, const float* psi_pre, const float* red1, const float* gamma1,
                   const float* mean1, const float* invstd1, const aau_bf16* zg,
                   const aau_bf16* zx, const float* sg, const float* hg, const float* sx,
                   const float* hx, const float* mean_g, const float* invstd_g,
                   const float* mean_x, const float* invstd_x, const float* wpsi,
-                  aau_bf16* ds, float* dwpsi, float* redg, float* redx, float* dgamma1,
+                  aau_bf16* ds, float* dwpsi_rep, float* redg, float* redx, float* dgamma1,
                   float* dbeta1, int64_t M, int F, void* stream);
-/* backward step 3: dzg/dzx from ds (BN backward without ReLU for both branches)            */
+/* backward step 3: dzg/dzx from ds (BN backward without ReLU for both branches);           */
+/* dwpsi[f] += sum over replicas of dwpsi_rep (dwpsi may be NULL)                            */
 int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_bf16* zx,
                   const float* gamma_g, const float* mean_g, const float* invstd_g,
                   const float* redg, const float* gamma_x, const float* mean_x,
                   const float* invstd_x, const float* redx, aau_bf16* dzg, aau_bf16* dzx,
                   float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x,
-                  int64_t M, int F, void* stream);
+                  const float* dwpsi_rep, float* dwpsi, int64_t M, int F, void* stream);
 
 /* ---- out_conv: Conv2d(C, 1, 1) with bias (pipeline:122) -------------------------------- */
 int aau_outconv_fwd(const aau_bf16* y, int y_pitch, const float* w, const float* b,

@@ -35,3 +35,19 @@ ta = timeit(lambda: ops.bn_bwd_apply(z, C, dz, C, gamma, mean, invstd, red, dg, 
 tw = timeit(lambda: ops.conv1_wgrad(x, dz, dw, N, H, W, C))
 tf = timeit(lambda: ops.bn_bwd_apply_conv1(z, C, gamma, mean, invstd, red, dg, db, N, H, W, C, dy, C, scale, shift, x, dw, ws))
 print(f"bn_bwd_apply {ta:.1f} us + conv1_wgrad {tw:.1f} us = {ta + tw:.1f} us;  fused {tf:.1f} us")
+
+# ---- attention-gate backward, middle pass (u2 / u3 / u4 shapes) ----
+for name, Mg, Fi in (("u2", 8 * 256 * 256, 48), ("u3", 8 * 128 * 128, 96), ("u4", 8 * 64 * 64, 192)):
+    R = ops.STAT_REPLICAS
+    f32 = lambda *s: torch.randn(*s, device="cuda")
+    dq, psi_pre = f32(Mg), f32(Mg)
+    zg, zx = f32(Mg, Fi).to(torch.bfloat16), f32(Mg, Fi).to(torch.bfloat16)
+    dsb = torch.empty(Mg, Fi, device="cuda", dtype=torch.bfloat16)
+    one = lambda: torch.ones(1, device="cuda")
+    vec = lambda: torch.rand(Fi, device="cuda") + 0.5
+    red1, redg, redx = torch.zeros(R, 2, device="cuda"), torch.zeros(R, 2, Fi, device="cuda"), torch.zeros(R, 2, Fi, device="cuda")
+    args = (dq, psi_pre, red1, one(), one(), one(), zg, zx, vec(), vec(), vec(), vec(), vec(), vec(), vec(), vec(), vec(),
+            dsb, torch.zeros(R, Fi, device="cuda"), redg, redx, one(), one(), Mg, Fi)
+    t = timeit(lambda: ops.gate_bwd2(*args))
+    gb = (Mg * Fi * 2 * 3 + Mg * 8) / 1e9
+    print(f"gate_bwd2 {name}: {t:.1f} us  ({gb / t * 1e3:.2f} TB/s)")

@@ -263,13 +263,14 @@ def test_attention_gate_elementwise_forward_backward(ops, Fi, C):
     ops.gate_bwd1(dev(bf(dout)), C, xd, C, al, psi_pre, sm1, si1, dx, C, dq, red1, M, C)
     ds = zeros(M, Fi, dtype=torch.bfloat16)
     dw, redg, redx = zeros(Fi), zeros(ops.STAT_REPLICAS, 2, Fi), zeros(ops.STAT_REPLICAS, 2, Fi)
+    dwrep = zeros(ops.STAT_REPLICAS, Fi)
     dg1, db1 = zeros(1), zeros(1)
     ops.gate_bwd2(dq, psi_pre, red1, d(P["g1"]), sm1, si1, zgd, zxd, sg, hg, sx, hx, d(mg), d(ig), d(mx), d(ix),
-                  d(P["w"]), ds, dw, redg, redx, dg1, db1, M, Fi)
+                  d(P["w"]), ds, dwrep, redg, redx, dg1, db1, M, Fi)
     dzg, dzx = zeros(M, Fi, dtype=torch.bfloat16), zeros(M, Fi, dtype=torch.bfloat16)
     dgg, dbg, dgx, dbx = zeros(Fi), zeros(Fi), zeros(Fi), zeros(Fi)
     ops.gate_bwd3(ds, zgd, zxd, d(P["gg"]), d(mg), d(ig), redg, d(P["gx"]), d(mx), d(ix), redx, dzg, dzx,
-                  dgg, dbg, dgx, dbx, M, Fi)
+                  dgg, dbg, dgx, dbx, dwrep, dw, M, Fi)
     torch.cuda.synchronize()
     # the x gradient has two parts; this kernel chain produces the direct one (dout*alpha)
     assert rel_err(dx.cpu(), (dout * alpha.detach())) < 1e-2
