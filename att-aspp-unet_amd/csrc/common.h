@@ -84,6 +84,16 @@ struct ProfScope {  // brackets one launch with events when profiling is on
     hipStream_t stream;
 };
 
+// BatchNorm-backward reduce fused into a data-gradient epilogue (conv3x3.hip, C3Args)
+struct BnRedArgs {
+    const unsigned short* z;
+    int zp;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+};
+
 // split-K reduction shared by wgrad.hip / wgrad3x3.hip (kernel in wgrad.hip)
 struct WRedArgs {
     const float* ws;

@@ -29,12 +29,42 @@ struct C3Args {
     const float* scale;
     const float* shift;
     float* stats;
+    // BatchNorm-backward reduce of the layer that PRODUCED this conv's input, fused into the data-gradient
+    // epilogue (bn_z != null): stats[r][0][c] += sum g, stats[r][1][c] += sum g * zhat with
+    // g = [bn_z*bn_scale+bn_shift > 0] * bf16(dst), zhat = (bn_z - bn_mean) * bn_invstd   (= aau_bn_bwd_reduce)
+    const unsigned short* bn_z;
+    int bn_zp;
+    const float* bn_scale;
+    const float* bn_shift;
+    const float* bn_mean;
+    const float* bn_invstd;
     int nchunk;          // Cpad / 32
     unsigned src_bytes, wpk_bytes;
     int tiles_x, tiles_y;
 };
 
 __device__ __forceinline__ int swz32(int row, int lc) { return lc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
+
+// epilogue statistics of one accumulator quad (4 consecutive channels q.. of one pixel): forward = (sum v, sum v^2);
+// fused BatchNorm-backward reduce = (sum g, sum g*zhat), see C3Args
+__device__ __forceinline__ void epi_stats(const C3Args& a, int64_t pixel, int q, const float v[4], float s1[4], float s2[4]) {
+    if (a.bn_z) {
+        const u32x2 zq = *(const u32x2*)(a.bn_z + pixel * a.bn_zp + q);
+        const float z[4] = {__uint_as_float(zq[0] << 16), __uint_as_float(zq[0] & 0xffff0000u),
+                            __uint_as_float(zq[1] << 16), __uint_as_float(zq[1] & 0xffff0000u)};
+        const f32x4 sc = *(const f32x4*)(a.bn_scale + q), sh = *(const f32x4*)(a.bn_shift + q);
+        const f32x4 mu = *(const f32x4*)(a.bn_mean + q), is = *(const f32x4*)(a.bn_invstd + q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float g = (z[r] * sc[r] + sh[r] > 0.f) ? bf2f(f2bf(v[r])) : 0.f;
+            s1[r] += g;
+            s2[r] += g * ((z[r] - mu[r]) * is[r]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+    }
+}
 
 // s_waitcnt takes an immediate; the pipeline below only ever needs these four counts per tile shape
 template <int N>
@@ -258,10 +288,7 @@ __global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
-            if (want_stats) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s1[ni][r] += v[r]; s2[ni][r] += v[r] * v[r]; }
-            }
+            if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
             if (a.bias) {
                 const f32x4 b = *(const f32x4*)(a.bias + q);
 #pragma unroll
@@ -497,10 +524,7 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
-            if (want_stats) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s1[ni][r] += v[r]; s2[ni][r] += v[r] * v[r]; }
-            }
+            if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
             if (a.bias) {
                 const f32x4 b = *(const f32x4*)(a.bias + q);
 #pragma unroll
@@ -704,10 +728,7 @@ __global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int n
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
-                if (want_stats) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { s1[ni][r] += v[r]; s2[ni][r] += v[r] * v[r]; }
-                }
+                if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
                 if (a.bias) {
                     const f32x4 b = *(const f32x4*)(a.bias + q);
 #pragma unroll
@@ -764,10 +785,14 @@ bool conv3x3_applicable(const aau_conv_desc* d) {
 
 int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
                    const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
-                   hipStream_t s) {
+                   const BnRedArgs* bn, hipStream_t s) {
     C3Args a;
     a.d = *d;
     a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
+    a.bn_z = bn ? bn->z : nullptr;
+    a.bn_zp = bn ? bn->zp : 0;
+    a.bn_scale = bn ? bn->scale : nullptr; a.bn_shift = bn ? bn->shift : nullptr;
+    a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
     a.nchunk = d->Cpad / 32;
     a.src_bytes = src_bytes;
     a.wpk_bytes = wpk_bytes;

@@ -346,7 +346,9 @@ class Plan:
         return rec
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
-    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0):
+    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, feeds=None):
+        """``feeds``: record of the ConvBNReLU whose output is this layer's ONLY consumer input (din is its full
+        output gradient): its BatchNorm-backward reduce is then fused into this layer's data-gradient epilogue."""
         cv, bn, w = r["cv"], r["bn"], r["w"]
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
@@ -355,8 +357,9 @@ class Plan:
         dz = None if fuse1 else self.new(M, cv.O)
         if dpool is None:
             # no pooling: the reduce pass only accumulates, the apply pass recomputes the ReLU / dropout mask
-            b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"], w["mean"],
-                  w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
+            if not r.get("reduced_by_consumer", False):
+                b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"],
+                      w["mean"], w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
             if fuse1:
                 # first layer: no input gradient, so the apply pass feeds the weight gradient directly
                 b.add("aau_bn_bwd_apply_conv1", r["z"], cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
@@ -381,7 +384,14 @@ class Plan:
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate)
-            b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, None)
+            if (feeds is not None and not self.eng.no_fuse_bnred and not feeds["drop"] and dinp == feeds["cv"].O
+                    and ops.conv_is_halo3x3(dd)):
+                fw = feeds["w"]
+                b.add("aau_conv_igemm_bnred", dd, dz, cv.pk_d, din, feeds["z"], feeds["cv"].O, fw["scale"], fw["shift"],
+                      fw["mean"], fw["invstd"], fw["red"])
+                feeds["reduced_by_consumer"] = True
+            else:
+                b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, None)
         return dz
 
     # ---- graph ----
@@ -512,7 +522,7 @@ class Plan:
         for blk in reversed(dec):            # u1, u2, u3, u4
             lv, Co, Mo, ho, wo, hi, wi = blk["lv"], blk["Co"], blk["Mo"], blk["ho"], blk["wo"], blk["hi"], blk["wi"]
             dya = self.new(Mo, Co)
-            self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co)
+            self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co, feeds=blk["ra"])
             dcat = self.new(Mo, 2 * Co)
             self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=2 * Co)
             if lv == 0:
@@ -580,7 +590,7 @@ class Plan:
             else:
                 dsk, dskp = dskip[lv], Cs[lv]
             dya = self.new(Ms[lv], Cs[lv])
-            self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv])
+            self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv], feeds=ra)
             if lv > 0:
                 dprev = self.new(Ms[lv], Cs[lv - 1])
                 self.cbr_bwd(ra, dya, Cs[lv], din=dprev, dinp=Cs[lv - 1])
@@ -630,7 +640,10 @@ class Engine:
         self.bucket_cb = None   # set by the data-parallel wrapper: name -> callable
         import os
         self.overlap_wgrad = os.environ.get("AAU_OVERLAP_WGRAD", "0") == "1"   # measured null on MI355X (A/B, same device)
-        self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switch
+        self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switches
+        # BN-backward reduce inside the consumer's data-gradient epilogue (aau_conv_igemm_bnred): measured a wash
+        # (elementwise -0.41 ms, conv +0.43 ms per step: the epilogue's extra z read is not hidden), so opt-in
+        self.no_fuse_bnred = os.environ.get("AAU_FUSE_BNRED", "0") != "1"
 
     def next_seed(self) -> int:
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF

@@ -52,6 +52,15 @@ def conv_igemm(desc: ConvDesc, src, wpk, dst, bias=None, scale=None, shift=None,
                                _p(stats), _stream()), "aau_conv_igemm")
 
 
+def conv_is_halo3x3(desc: ConvDesc) -> bool:
+    return bool(fn("aau_conv_is_halo3x3")(C.byref(desc)))
+
+
+def conv_igemm_bnred(desc: ConvDesc, src, wpk, dst, bn_z, bn_zp, bn_scale, bn_shift, bn_mean, bn_invstd, red):
+    check(fn("aau_conv_igemm_bnred")(C.byref(desc), _p(src), _p(wpk), _p(dst), _p(bn_z), bn_zp, _p(bn_scale),
+                                     _p(bn_shift), _p(bn_mean), _p(bn_invstd), _p(red), _stream()), "aau_conv_igemm_bnred")
+
+
 def conv_wgrad_ws_bytes(desc: ConvDesc) -> int:
     n = C.c_int64(0)
     check(fn("aau_conv_wgrad_ws_bytes")(C.byref(desc), C.byref(n)), "aau_conv_wgrad_ws_bytes")

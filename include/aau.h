@@ -87,6 +87,19 @@ int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    aau_bf16* dst, const float* bias, const float* scale, const float* shift,
                    float* stats, void* stream);
 
+/* Data-gradient conv (3x3, pad 1, stride 1, H and W multiples of 16: aau_conv_is_halo3x3)  */
+/* with the BatchNorm-backward REDUCE of the layer that produced the conv's input fused    */
+/* into the epilogue: dst = the gradient w.r.t. that layer's output y = relu(bn(z)), and    */
+/* red[r][0][c] += sum g, red[r][1][c] += sum g*zhat with g = [bn_z*bn_scale+bn_shift > 0]  */
+/* * bf16(dst), zhat = (bn_z - bn_mean)*bn_invstd -- exactly what aau_bn_bwd_reduce(dz=NULL) */
+/* would accumulate from dst; aau_bn_bwd_apply(dy = dst, ...) follows.  Saves one read of   */
+/* dst and one launch per ConvBNReLU whose output feeds a single 3x3 conv.                  */
+int aau_conv_is_halo3x3(const aau_conv_desc* d);
+int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
+                         aau_bf16* dst, const aau_bf16* bn_z, int bn_z_pitch,
+                         const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                         const float* bn_invstd, float* red, void* stream);
+
 /* Weight-gradient of the same convolutions (ATen convolution_backward, weight part):   */
 /* dw[q][t][c] += sum_m dz[m][q] * src[gather(m,t)][c]   (the caller zeroes dw)         */
 /* d->Cout = channels of dz (pitch d->dst_pitch), d->Cin = channels of src.             */
