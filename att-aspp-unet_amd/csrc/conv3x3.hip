@@ -777,6 +777,202 @@ __global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int n
     }
 }
 
+// Two patch streams per workgroup (8 waves = 2 groups of 4) SHARING one resident weight image: 2 waves per SIMD for the
+// layers whose weights leave room for four halo buffers (Cin <= 64, 48 output channels: 54 KiB + 96 KiB).  At one
+// wave per SIMD the patch time of the kernel above is a serial sum (MFMA issue, epilogue VALU, LDS reads, stores:
+// each 13-22 % by ablation); the second group fills those gaps.  Both groups run the same number of steps (host
+// guarantees npatch % (2 * gridDim.x) == 0), so the workgroup-wide barriers line up.
+__global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int npatch) {
+    constexpr int BQ = 48;
+    constexpr int BK = 32, HW_ = 18, HROWS = HW_ * HW_, HPAD = 384, NI = BQ / 16, MI = 4, HL = 6;
+    constexpr int HALO_E = HPAD * BK, WT_E = BQ * BK;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];   // [2 groups][2 halo][nchunk*9 weight tiles]
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave8 >> 2, wave = wave8 & 3;   // group, wave within the group
+    auto sH = [&](int b) -> unsigned short* { return dsm + (grp * 2 + b) * HALO_E; };
+    auto sWt = [&](int chunk, int tap) -> unsigned short* { return dsm + 4 * HALO_E + (chunk * 9 + tap) * WT_E; };
+    const int lane = tid & 63;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int q0 = blockIdx.y * BQ;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+
+    // ---- weights: all (chunk, tap) tiles of this channel tile, once ----
+    {
+        const int ntile = a.nchunk * 9;
+        constexpr int PIECES = BQ * 4;                        // 16-B pieces per tile
+        for (int base = 0; base < ntile * PIECES; base += 512) {   // uniform trip count; wave-linear 1 KiB pieces
+            const int p = base + tid;
+            const int tile = p / PIECES, r = p - tile * PIECES;
+            const int row = r >> 2, lc = swz32(row, r & 3);
+            const int chunk = tile / 9, tap = tile - chunk * 9;
+            const bool ok = tile < ntile && q0 + row < d.Cout;
+            const unsigned v = ok ? (unsigned)((((q0 + row) * 9 + tap) * d.Cpad + chunk * BK + lc * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dsm + 4 * HALO_E + (base + wave8 * 64) * 8), 16, (int)v, 0, 0, 0);
+        }
+    }
+    // ---- halo roles (patch independent part) ----
+    int hy_[HL], hx_[HL], lc_[HL];
+    bool htail[HL];
+    const int tail_c0 = (a.nchunk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+        const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+        lc_[i] = swz32(hr, lane & 3);
+        hy_[i] = hr < HROWS ? hr / HW_ : -100000;
+        hx_[i] = hr % HW_;
+        htail[i] = tail_c0 + lc_[i] * 8 < d.Cin;
+    }
+    const bool has_tail = d.Cpad != d.Cin;
+    auto patch_origin = [&](int patch, int& n, int& y0, int& x0) {
+        const int px_t = patch % a.tiles_x;
+        const int t2 = patch / a.tiles_x;
+        const int py_t = t2 % a.tiles_y;
+        n = t2 / a.tiles_y; y0 = py_t * 16; x0 = px_t * 16;
+    };
+    auto issue_halo = [&](int buf, int patch, int chunk) {
+        int n, y0, x0;
+        patch_origin(patch, n, y0, x0);
+        const bool last = has_tail && chunk == a.nchunk - 1;
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+            const int y = y0 - 1 + hy_[i], x = x0 - 1 + hx_[i];
+            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
+            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * 4 + wave) * 16 * BK), 16, (int)v,
+                                                     chunk * BK * 2, 0, 0);
+        }
+    };
+
+    const bool want_stats = a.stats != nullptr;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+
+    const int first = blockIdx.x * 2 + grp, stride = gridDim.x * 2;
+    const bool full_tiles = q0 + BQ <= d.Cout;   // every lane issues all NI*MI stores of a patch
+    int t = 0;
+    if (first < npatch) issue_halo(0, first, 0);
+    for (int patch = first; patch < npatch; patch += stride) {
+        f32x4 acc[NI][MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < a.nchunk; ++chunk, ++t) {
+            // halo(t) (and, the first time, the weights) must have landed.  At the first chunk of a later
+            // patch the only younger operations are the previous patch's NI*MI output stores per lane
+            // (vmcnt retires in issue order), which may stay in flight.
+            if (t > 0 && chunk == 0 && full_tiles) {
+                if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            {   // prefetch the next (patch, chunk) tile into the other buffer
+                int np = patch, nc = chunk + 1;
+                if (nc == a.nchunk) { nc = 0; np += stride; }
+                if (np < npatch) issue_halo((t + 1) & 1, np, nc);
+            }
+            const unsigned short* hbase = sH(t & 1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ty = tap / 3, tx = tap % 3;
+                const unsigned short* wbase = sWt(chunk, tap);
+                bf16x8 wf[NI], af[MI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = ni * 16 + fr;
+                    wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
+                    af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
+                }
+#ifdef AAU_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#ifdef AAU_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+        }
+        // ---- per-patch epilogue ----
+        int n, y0, x0;
+        patch_origin(patch, n, y0, x0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int y = y0 + wave * MI + mi, x = x0 + fr;
+            const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int q = q0 + ni * 16 + 4 * fk;
+                if (q >= d.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+                if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
+                if (a.bias) {
+                    const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b[r];
+                }
+                if (a.scale) {
+                    const f32x4 sc = *(const f32x4*)(a.scale + q);
+                    const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+                }
+                if (d.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                u32x2 pk;
+                pk[0] = pack2(v[0], v[1]);
+                pk[1] = pack2(v[2], v[3]);
+                *(u32x2*)(a.dst + pixel * d.dst_pitch + q) = pk;
+            }
+        }
+    }
+    if (want_stats) {
+        float* sst = (float*)dsm;   // halo buffers are dead
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < 2 * BQ) sst[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0) {
+                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
+                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                }
+            }
+        }
+        __syncthreads();
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        if (tid < 2 * BQ) {
+            const int which = tid / BQ, ql = tid - which * BQ;
+            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        }
+    }
+}
+
 // true when the halo kernel applies to this descriptor
 bool conv3x3_applicable(const aau_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->shuffle2x2 &&
@@ -807,6 +1003,22 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
         const size_t wbytes = ((size_t)a.nchunk * 9 * BQ * 64 + 4095) / 4096 * 4096;
         const size_t lds = (size_t)2 * 384 * 64 + wbytes;
         const int ntq = (d->Cout + BQ - 1) / BQ;
+        // two patch streams sharing the weights (2 waves per SIMD) where four halo buffers fit beside them
+        {
+            const size_t wb2 = ((size_t)a.nchunk * 9 * 48 * 64 + 8191) / 8192 * 8192;
+            const size_t lds2 = (size_t)4 * 384 * 64 + wb2;
+            const int gx2 = npatch / 2 < 256 ? npatch / 2 : 256;
+            if (narrow && ntq == 1 && !d->accumulate && lds2 <= 160 * 1024 && npatch >= 2048 && npatch % (2 * gx2) == 0 &&
+                !getenv("AAU_NO_RESW") && !getenv("AAU_NO_RESW2")) {
+                static bool attr2 = false;
+                if (!attr2) {
+                    hipFuncSetAttribute((const void*)conv3x3_resw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr2 = true;
+                }
+                hipLaunchKernelGGL(conv3x3_resw2_kernel, dim3(gx2, 1), dim3(512), lds2, s, a, npatch);
+                return check_launch("aau_conv_igemm(3x3 resident weights, two patch streams)");
+            }
+        }
         if (!d->accumulate && lds <= 160 * 1024 && npatch >= 1024 && ntq <= 2 && !getenv("AAU_NO_RESW")) {
             static bool attr48 = false, attr96 = false;
             if (narrow && !attr48) {

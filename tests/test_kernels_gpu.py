@@ -61,9 +61,11 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", [(5, 256, 256, 48, 48), (4, 256, 272, 96, 48), (4, 272, 256, 48, 96), (5, 256, 256, 8, 56)])
+@pytest.mark.parametrize("case", [(5, 256, 256, 48, 48), (4, 256, 272, 96, 48), (4, 272, 256, 48, 96), (5, 256, 256, 8, 56),
+                                  # >= 2048 patches, Cin <= 64, <= 48 output channels: two patch streams per workgroup
+                                  (8, 256, 256, 48, 48), (8, 256, 256, 64, 40), (16, 256, 128, 8, 48)])
 def test_resident_weight_3x3_path(ops, case):
-    """>= 1024 patches of 16x16 and a small weight matrix select the persistent resident-weight kernel."""
+    """>= 1024 patches of 16x16 and a small weight matrix select the persistent resident-weight kernels."""
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(sum(case))
     x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
@@ -168,7 +170,7 @@ def test_igemm_dgrad(ops, case):
 
 
 # (N, H, W, channels of dz, channels of the produced gradient): grouped-tap kernel <96> / <48>, resident-weight <48> / <96>
-BNRED_CASES = [(2, 32, 32, 96, 96), (2, 32, 48, 96, 40), (4, 256, 256, 48, 48), (4, 256, 256, 48, 96)]
+BNRED_CASES = [(2, 32, 32, 96, 96), (2, 32, 48, 96, 40), (4, 256, 256, 48, 48), (4, 256, 256, 48, 96), (8, 256, 256, 48, 48)]
 
 
 @pytest.mark.parametrize("case", BNRED_CASES)
