@@ -587,9 +587,11 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
 // walks over patches: per (patch, chunk) it waits for ONE halo tile (the next one is already in
 // flight), runs all 9 taps with no barrier in between, and keeps the BatchNorm statistics in
 // registers across patches (one set of atomics per workgroup at the very end).
-template <int BQ>
-__global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int npatch) {
-    constexpr int BK = 32, HW_ = 18, HROWS = HW_ * HW_, HPAD = 384, NI = BQ / 16, MI = 4, HL = 6;
+// NW = 4: one wave per SIMD, 4 patch rows per wave; NW = 8: two waves per SIMD, 2 patch rows per wave (same LDS
+// image, 60 % more LDS reads per MFMA, but the serial phases of one wave overlap with its SIMD partner's).
+template <int BQ, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, int npatch) {
+    constexpr int BK = 32, HW_ = 18, HROWS = HW_ * HW_, HPAD = 384, NI = BQ / 16, MI = 16 / NW, HL = 24 / NW;
     constexpr int HALO_E = HPAD * BK, WT_E = BQ * BK;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];   // [2 halo][nchunk*9 weight tiles]
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int n
     {
         const int ntile = a.nchunk * 9;
         constexpr int PIECES = BQ * 4;                        // 16-B pieces per tile
-        for (int base = 0; base < ntile * PIECES; base += 256) {   // uniform trip count; wave-linear 1 KiB pieces
+        for (int base = 0; base < ntile * PIECES; base += 64 * NW) {   // uniform trip count; wave-linear 1 KiB pieces
             const int p = base + tid;
             const int tile = p / PIECES, r = p - tile * PIECES;
             const int row = r >> 2, lc = swz32(row, r & 3);
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int n
     const int tail_c0 = (a.nchunk - 1) * BK;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-        const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+        const int hr = (i * NW + wave) * 16 + (lane >> 2);
         lc_[i] = swz32(hr, lane & 3);
         hy_[i] = hr < HROWS ? hr / HW_ : -100000;
         hx_[i] = hr % HW_;
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int n
             const int y = y0 - 1 + hy_[i], x = x0 - 1 + hx_[i];
             const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
             const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * 4 + wave) * 16 * BK), 16, (int)v,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * NW + wave) * 16 * BK), 16, (int)v,
                                                      chunk * BK * 2, 0, 0);
         }
     };
@@ -674,7 +676,8 @@ __global__ __launch_bounds__(256) void conv3x3_resw_kernel(const C3Args a, int n
             // patch the only younger operations are the previous patch's NI*MI output stores per lane
             // (vmcnt retires in issue order), which may stay in flight.
             if (t > 0 && chunk == 0 && full_tiles) {
-                if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -999,8 +1002,8 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     // resident-weight persistent variant: small weight matrix, many patches, no read-modify-write epilogue
     {
         const int npatch = a.tiles_x * a.tiles_y * d->N;
-        // two halo buffers + all weight tiles, the latter rounded up to whole 4-KiB staging rounds
-        const size_t wbytes = ((size_t)a.nchunk * 9 * BQ * 64 + 4095) / 4096 * 4096;
+        // two halo buffers + all weight tiles, the latter rounded up to whole staging rounds
+        const size_t wbytes = ((size_t)a.nchunk * 9 * BQ * 64 + 8191) / 8192 * 8192;   // whole staging rounds of 512 threads
         const size_t lds = (size_t)2 * 384 * 64 + wbytes;
         const int ntq = (d->Cout + BQ - 1) / BQ;
         // two patch streams sharing the weights (2 waves per SIMD) where four halo buffers fit beside them
@@ -1022,16 +1025,22 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
         if (!d->accumulate && lds <= 160 * 1024 && npatch >= 1024 && ntq <= 2 && !getenv("AAU_NO_RESW")) {
             static bool attr48 = false, attr96 = false;
             if (narrow && !attr48) {
-                hipFuncSetAttribute((const void*)conv3x3_resw_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)conv3x3_resw_kernel<48, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)conv3x3_resw_kernel<48, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr48 = true;
             }
             if (!narrow && !attr96) {
-                hipFuncSetAttribute((const void*)conv3x3_resw_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)conv3x3_resw_kernel<96, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)conv3x3_resw_kernel<96, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr96 = true;
             }
             const int gx = npatch < 256 / ntq ? npatch : 256 / ntq;
-            if (narrow) hipLaunchKernelGGL((conv3x3_resw_kernel<48>), dim3(gx, ntq), dim3(256), lds, s, a, npatch);
-            else hipLaunchKernelGGL((conv3x3_resw_kernel<96>), dim3(gx, ntq), dim3(256), lds, s, a, npatch);
+            // 8 waves on one patch (2 per SIMD): -10...20 % against 4 waves on every layer that takes this path
+            const bool w8 = getenv("AAU_RESW_W4") == nullptr;
+            if (narrow && w8) hipLaunchKernelGGL((conv3x3_resw_kernel<48, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
+            else if (narrow) hipLaunchKernelGGL((conv3x3_resw_kernel<48, 4>), dim3(gx, ntq), dim3(256), lds, s, a, npatch);
+            else if (w8) hipLaunchKernelGGL((conv3x3_resw_kernel<96, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
+            else hipLaunchKernelGGL((conv3x3_resw_kernel<96, 4>), dim3(gx, ntq), dim3(256), lds, s, a, npatch);
             return check_launch("aau_conv_igemm(3x3 resident weights)");
         }
     }
