@@ -50,6 +50,7 @@ _SIGS = {
     "aau_prof_collect": [P, P, P],
     "aau_conv_igemm": [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P],
     "aau_conv_is_halo3x3": [C.POINTER(ConvDesc)],
+    "aau_traverse": [I],
     "aau_conv_igemm_bnred": [C.POINTER(ConvDesc), P, P, P, P, I, P, P, P, P, P, P],
     "aau_conv_wgrad": [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P],
     "aau_conv_wgrad_ws_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int64)],

@@ -4,6 +4,7 @@
 // fixed channel group so per-channel reductions live in registers, are combined through
 // LDS per block and leave the block as one fp32 atomic per channel into one of
 // AAU_STAT_REPLICAS accumulator copies (spreads same-address contention).
+#include <stdlib.h>
 #include "common.h"
 
 namespace aau {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const unsigned short* z, in
     ldf8(scale + c, sc);
     ldf8(shift + c, sh);
     const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
     for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
         const int64_t ms = bhw > 0 ? m / bhw : m;
         float f[8];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const unsigned short* 
     float sc[8], sh[8];
     ldf8(scale + c, sc);
     ldf8(shift + c, sh);
-    const int64_t i0 = (int64_t)blockIdx.x * ipb, i1 = min(total, i0 + ipb);
+    const int64_t i0 = slice_begin(ipb), i1 = min(total, i0 + ipb);
     for (int64_t mo = i0 + pl; mo < i1; mo += mp.PL) {
         const int xo = (int)(mo % Wo);
         const int64_t t = mo / Wo;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         ldf8(scale + c, sc); ldf8(shift + c, sh); ldf8(mean + c, mu); ldf8(invstd + c, is);
         const int Ho = H >> 1, Wo = W >> 1;
         const int64_t nitems = POOL ? (int64_t)N * Ho * Wo : (int64_t)N * H * W;
-        const int64_t i0 = (int64_t)blockIdx.x * items_per_block;
+        const int64_t i0 = slice_begin(items_per_block);
         const int64_t i1 = min(nitems, i0 + items_per_block);
         for (int64_t it = i0 + pl; it < i1; it += mp.PL) {
             if constexpr (POOL) {
@@ -311,7 +312,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
         k2[j] = sm[C + c + j] / (float)M;
     }
     const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    // rev: workgroups walk the tensor from its END (the part the preceding reduce pass touched last, i.e. what the
+    // 256-MiB Infinity Cache still holds when the tensor is larger than the cache)
+    const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
     for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
         float zz[8], g[8];
         unpack8(ld16(z + m * zp + c), zz);
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 5; ++k) acc[j][k] = f32x2{0.f, 0.f};
-        const int m0 = blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        const int m0 = (int)slice_begin(ppb), m1 = min(M, m0 + ppb);
         // (row, column) of the thread's pixel, advanced incrementally (no division in the loop)
         int m = m0 + pl;
         int xx = m % W, row = m / W;            // row = n*H + y
@@ -520,6 +523,7 @@ extern "C" int aau_bn_act(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pit
     ProfScope prof(2, 0, (hipStream_t)stream);
     int64_t blocks, ppb;
     rows_split(M, CGMap(C).PL, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, z_pitch, y,
                        y_pitch, scale, shift, M, C, relu, bcast_hw, drop_p, drop_seed, ppb);
     return check_launch("aau_bn_act");
@@ -534,6 +538,7 @@ extern "C" int aau_bn_act_pool(const aau_bf16* z, int z_pitch, aau_bf16* y, int 
     ProfScope prof(2, 0, (hipStream_t)stream);
     int64_t blocks, ipb;
     rows_split((int64_t)N * (H / 2) * (W / 2), CGMap(C).PL, &blocks, &ipb);
+    if (next_traversal()) ipb = -ipb;
     hipLaunchKernelGGL(bn_act_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, z_pitch, y,
                        y_pitch, p, p_pitch, scale, shift, N, H, W, C, ipb);
     return check_launch("aau_bn_act_pool");
@@ -570,8 +575,9 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
         const int64_t items = (int64_t)N * (H / 2) * (W / 2);
         int64_t blocks = (items + mp.PL * 4 - 1) / (mp.PL * 4);
         if (blocks > 2048) blocks = 2048;
-        const int64_t ipb = (items + blocks - 1) / blocks;
+        int64_t ipb = (items + blocks - 1) / blocks;
         blocks = (items + ipb - 1) / ipb;
+        if (next_traversal()) ipb = -ipb;
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
                            z_pitch, dy, dy_pitch, dpool, dpool_pitch, dz, dz_pitch, scale, shift, save_mean,
                            save_invstd, red, N, H, W, C, relu, drop_p, drop_seed, ipb);
@@ -579,8 +585,9 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
         const int64_t items = (int64_t)N * H * W;
         int64_t blocks = (items + mp.PL * 8 - 1) / (mp.PL * 8);
         if (blocks > 2048) blocks = 2048;
-        const int64_t ipb = (items + blocks - 1) / blocks;
+        int64_t ipb = (items + blocks - 1) / blocks;
         blocks = (items + ipb - 1) / ipb;
+        if (next_traversal()) ipb = -ipb;
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
                            z_pitch, dy, dy_pitch, dpool, dpool_pitch, dz, dz_pitch, scale, shift, save_mean,
                            save_invstd, red, N, H, W, C, relu, drop_p, drop_seed, ipb);
@@ -599,6 +606,7 @@ extern "C" int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, in
     ProfScope prof(2, 0, (hipStream_t)stream);
     int64_t blocks, ppb;
     rows_split(M, CGMap(C).PL, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, z, z_pitch, dz,
                        dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, M, C, dy, dy_pitch, scale, shift,
                        relu, drop_p, drop_seed, ppb);
@@ -619,10 +627,11 @@ extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const floa
     int64_t blocks, ppb;
     AAU_REQUIRE(C <= 1024, "aau_bn_bwd_apply_conv1: C=%d too wide for one workgroup", C);
     rows_split(M, 256 / (C >> 2), &blocks, &ppb);
+    const int ppb_signed = next_traversal() ? -(int)ppb : (int)ppb;
     zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * C * 9, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel, dim3((unsigned)blocks), dim3(256), (2 * C + 9 * C) * sizeof(float),
                        (hipStream_t)stream, z, z_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, (int)M, C, dy,
-                       dy_pitch, scale, shift, x, H, W, ws, (int)ppb);
+                       dy_pitch, scale, shift, x, H, W, ws, ppb_signed);
     hipLaunchKernelGGL(fold_conv1_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9);
     return check_launch("aau_bn_bwd_apply_conv1");
 }

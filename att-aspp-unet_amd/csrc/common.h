@@ -64,6 +64,15 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// First row of this workgroup's slice of a row-split launch.  A NEGATIVE rows-per-block encodes "walk the tensor
+// from its end" (aau_traverse): workgroup b then owns slice gridDim.x-1-b.  Makes rpb positive.
+template <typename T>
+__device__ __forceinline__ int64_t slice_begin(T& rpb) {
+    const bool rev = rpb < 0;
+    if (rev) rpb = -rpb;
+    return (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rpb;
+}
+
 // counter-based uniform in [0,1) for dropout: keyed by (seed, element index)
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
@@ -74,6 +83,7 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t idx) {
 }
 
 // ---- host side: errors + launch profiling ----
+int next_traversal();   // 1: this launch walks its tensors from the end (aau_traverse), see aau.h
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 

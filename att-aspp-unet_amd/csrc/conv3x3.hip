@@ -38,6 +38,7 @@ struct C3Args {
     const float* bn_shift;
     const float* bn_mean;
     const float* bn_invstd;
+    int rev;             // 1: walk the patches from the end (aau_traverse)
     int nchunk;          // Cpad / 32
     unsigned src_bytes, wpk_bytes;
     int tiles_x, tiles_y;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
     // tile order: channel tile fastest, then patches; bijective XCD remap (see igemm.hip)
     const int ntq = (d.Cout + BQ - 1) / BQ;
     const int nwg = gridDim.x;
-    int bid = blockIdx.x;
+    int bid = a.rev ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
     {
         const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
     const int lane = tid & 63;
     const int ntq = (d.Cout + BQ - 1) / BQ;
     const int nwg = gridDim.x;
-    int bid = blockIdx.x;
+    int bid = a.rev ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
     {
         const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
@@ -635,6 +636,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
     }
     const bool has_tail = d.Cpad != d.Cin;
     auto patch_origin = [&](int patch, int& n, int& y0, int& x0) {
+        if (a.rev) patch = npatch - 1 - patch;
         const int px_t = patch % a.tiles_x;
         const int t2 = patch / a.tiles_x;
         const int py_t = t2 % a.tiles_y;
@@ -832,6 +834,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
     }
     const bool has_tail = d.Cpad != d.Cin;
     auto patch_origin = [&](int patch, int& n, int& y0, int& x0) {
+        if (a.rev) patch = npatch - 1 - patch;
         const int px_t = patch % a.tiles_x;
         const int t2 = patch / a.tiles_x;
         const int py_t = t2 % a.tiles_y;
@@ -992,6 +995,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     a.bn_zp = bn ? bn->zp : 0;
     a.bn_scale = bn ? bn->scale : nullptr; a.bn_shift = bn ? bn->shift : nullptr;
     a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
+    a.rev = next_traversal();
     a.nchunk = d->Cpad / 32;
     a.src_bytes = src_bytes;
     a.wpk_bytes = wpk_bytes;

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void gate_psi_kernel(const unsigned short* zg,
     float v_sg[8], v_hg[8], v_sx[8], v_hx[8], v_w[8];
     if (active) { ldf8g(sg + c, v_sg); ldf8g(hg + c, v_hg); ldf8g(sx + c, v_sx); ldf8g(hx + c, v_hx); ldf8g(wpsi + c, v_w); }
     float t1 = 0.f, t2 = 0.f;
-    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
     for (int64_t mb = m0; mb < m1; mb += mp.PL) {
         const int64_t m = mb + pl;
         float acc = 0.f;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void gate_bwd1_kernel(const unsigned short* do
     const bool active = tid < mp.T;
     const float mu = mean1[0], is = invstd1[0];
     float t1 = 0.f, t2 = 0.f;
-    const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+    const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
     for (int64_t mb = m0; mb < m1; mb += mp.PL) {
         const int64_t m = mb + pl;
         float dot = 0.f, a = 0.f;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void gate_bwd2_kernel(
         float v_sg[8], v_hg[8], v_sx[8], v_hx[8], v_w[8], v_mg[8], v_ig[8], v_mx[8], v_ix[8];
         ldf8g(sg + c, v_sg); ldf8g(hg + c, v_hg); ldf8g(sx + c, v_sx); ldf8g(hx + c, v_hx); ldf8g(wpsi + c, v_w);
         ldf8g(mean_g + c, v_mg); ldf8g(invstd_g + c, v_ig); ldf8g(mean_x + c, v_mx); ldf8g(invstd_x + c, v_ix);
-        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         auto body = [&](int64_t m, float pp, float dqv, const u32x4& qa, const u32x4& qb) {
             const float ph = (pp - mu1) * is1;
             const float dp = k0 * (dqv - k1 - ph * k2);
@@ -322,8 +322,9 @@ extern "C" int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float*
     int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
-    const int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
+    int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
     b = (M + ppb - 1) / ppb;
+    if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(gate_psi_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, zg, zx, sg, hg, sx, hx,
                        wpsi, psi_pre, stats, M, F, ppb);
     return check_launch("aau_gate_psi");
@@ -353,8 +354,9 @@ extern "C" int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf1
     int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
-    const int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
+    int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
     b = (M + ppb - 1) / ppb;
+    if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(gate_bwd1_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dout, dout_pitch, x,
                        x_pitch, alpha, psi_pre, mean1, invstd1, dx, dx_pitch, dq, red1, M, C, ppb);
     return check_launch("aau_gate_bwd1");
@@ -377,8 +379,9 @@ extern "C" int aau_gate_bwd2(const float* dq, const float* psi_pre, const float*
     if (const char* e = getenv("AAU_GB2_PPT")) b = (M + (int64_t)mp.PL * atoi(e) - 1) / ((int64_t)mp.PL * atoi(e));   // experiment
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
-    const int64_t ppb = (M + b - 1) / b;
+    int64_t ppb = (M + b - 1) / b;
     b = (M + ppb - 1) / ppb;
+    if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(gate_bwd2_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dq, psi_pre, red1,
                        gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x, invstd_x, wpsi, ds,

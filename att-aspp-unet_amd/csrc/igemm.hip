@@ -45,6 +45,7 @@ struct IgemmArgs {
     int nchunk;  // Cpad / BK
     unsigned src_bytes;  // extent of the gather source (buffer descriptor range; out-of-range reads return 0)
     unsigned wpk_bytes;
+    int rev;             // 1: walk the tiles from the end (aau_traverse)
 };
 
 // SMALL = half-height pixel tile (64 x 96): for the 32x32-resolution layers (M = 8192) the regular tiling
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // tiles / neighbouring pixel tiles) share an XCD's L2.  Bijective remap.
     const int ntq = (d.Cout + BQ - 1) / BQ;
     const int nwg = gridDim.x;
-    int bid = blockIdx.x;
+    int bid = a.rev ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
     {
         const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
@@ -412,10 +413,12 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
     a.nchunk = d->Cpad / (bk64 ? 64 : 32);
     const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
     ProfScope prof(0, flops, (hipStream_t)stream);
+    a.rev = 0;
     if (conv3x3_applicable(d))
         return conv3x3_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, bn,
                               (hipStream_t)stream);
     AAU_REQUIRE(!bn, "aau_conv_igemm_bnred: only the halo-tiled 3x3 path carries the fused reduce (aau_conv_is_halo3x3)");
+    a.rev = next_traversal();
     const bool narrow = d->Cout <= 48;
     // long-K, few-tile problems (bridge at 32x32): halve the pixel tile to double the workgroup count
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((d->Cout + 95) / 96);

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* x, const fl
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
     if (tid < mp.T) {
         const int64_t M = (int64_t)N * H * W;
-        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
             const int xx = (int)(m % W);
             const int64_t t = m / W;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* x, const 
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc[j][k] = 0.f;
         const int64_t M = (int64_t)N * H * W;
-        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
             const int xx = (int)(m % W);
             const int64_t t = m / W;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const unsigned short* 
         float wv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) wv[j] = w[c + j];
-        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
             const float g = dl[m];
             float f[8], o[8];
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* src, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = 0.f;
     if (tid < mp.T) {
-        const int64_t m0 = (int64_t)blockIdx.x * ppb, m1 = min(M, m0 + ppb);
+        const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
             float f[8];
             unpack8(*(const u32x4*)(src + m * sp + c), f);
@@ -373,6 +373,7 @@ extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, float*
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows((int64_t)N * H * W, mp.PL, 16, 4096, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), (C * 9 + 256 * 8) * sizeof(float),
                        (hipStream_t)stream, x, w, z, stats, N, H, W, C, ppb);
@@ -386,6 +387,7 @@ extern "C" int aau_conv1_wgrad(const float* x, const aau_bf16* dz, float* dw, in
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows((int64_t)N * H * W, mp.PL, 32, 1024, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), C * 9 * sizeof(float),
                        (hipStream_t)stream, x, dz, dw, N, H, W, C, ppb);
@@ -411,6 +413,7 @@ extern "C" int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlog
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows(M, mp.PL, 16, 2048, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 4.0 * M * C, (hipStream_t)stream);
     zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * (C + 8), (hipStream_t)stream);
     hipLaunchKernelGGL(outconv_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, y_pitch,
@@ -463,6 +466,7 @@ extern "C" int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float*
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows(M, mp.PL, 16, 1024, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 0, (hipStream_t)stream);
     zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * (C + 8), (hipStream_t)stream);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, src_pitch, ws, M,

@@ -9,6 +9,16 @@ namespace aau {
 
 static thread_local char g_err[512] = "";
 
+// traversal hint (aau_traverse): 0 = off (always forward), 1 = alternate; g_rev = direction of the next launch
+static thread_local int g_trav_mode = 0, g_rev = 0;
+
+int next_traversal() {
+    if (!g_trav_mode) return 0;
+    const int r = g_rev;
+    g_rev ^= 1;
+    return r;
+}
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -69,6 +79,12 @@ ProfScope::~ProfScope() {
 
 extern "C" const char* aau_last_error(void) { return aau::g_err; }
 extern "C" int aau_version(void) { return 1; }
+
+extern "C" int aau_traverse(int alternate) {
+    aau::g_trav_mode = alternate != 0;
+    aau::g_rev = 0;
+    return AAU_OK;
+}
 
 extern "C" int aau_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(aau::g_prof_mu);

@@ -40,6 +40,7 @@ struct WgradArgs {
     int pix_per_split;  // multiple of the K-step
     int nsplit;
     int linear;         // 1: gather(m) == m (1x1, stride 1, pad 0)
+    int rev;            // 1: workgroups take the split ranges from the end (aau_traverse)
     float* ws;          // split-K slabs [workgroup][9 acc tiles][256 threads][4] (null: fp32 atomics into dw)
 };
 
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int T = d.KH * d.KW;
     const int ntq = (d.Cout + 48 * TQ - 1) / (48 * TQ);
     const int ntc = (d.Cin + 48 * TC - 1) / (48 * TC);
-    int bid = blockIdx.x;
+    int bid = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int lbid = bid;      // logical workgroup id = slab index
     const int split = bid % a.nsplit;
     bid /= a.nsplit;
     const int tap = bid % T;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int me = min(a.M, mb + a.pix_per_split);
     if (mb >= me) {  // uniform; never taken with the host's split sizes, but a slab must not stay unwritten
         if (a.ws)
-            for (int v = 0; v < 9; ++v) *(f32x4*)(a.ws + ((int64_t)blockIdx.x * 9 * 256 + v * 256 + threadIdx.x) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < 9; ++v) *(f32x4*)(a.ws + ((int64_t)lbid * 9 * 256 + v * 256 + threadIdx.x) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
 
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     if (a.ws) {
         // split-K partial: the accumulators leave in register layout (16 B per lane, 4 KiB per instruction and
         // workgroup); wg_reduce_kernel sums the slabs of a tile in a fixed order -> bitwise reproducible dw
-        float* slab = a.ws + (int64_t)blockIdx.x * (9 * 256 * 4);
+        float* slab = a.ws + (int64_t)lbid * (9 * 256 * 4);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -387,6 +389,7 @@ static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipS
         return AAU_E_INVALID;
     }
     a.ws = ws;
+    a.rev = next_traversal();
     hipLaunchKernelGGL((wgrad_kernel<TQ, TC>), dim3((unsigned)grid), dim3(256), 0, s, a);
     if (!ws) return check_launch("aau_conv_wgrad");
     WRedArgs r;

@@ -40,6 +40,7 @@ struct W3Args {
     int npatch;                  // N * (H/8) * (W/16)
     int patches_per_block, nsplit;
     int tiles_x, tiles_y;        // W/16, H/8
+    int rev;                     // 1: workgroups take the split ranges from the end (aau_traverse)
 };
 
 // QT = 16-channel q tiles per workgroup (3: 48 channels, 6: 96 channels); PR = patch rows per K-step.
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     const int lane = tid & 63;
 
     const int ntc = (d.Cin + 47) / 48;
-    int bid = blockIdx.x;
+    int bid = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int lbid = bid;      // logical workgroup id = slab index
     const int split = bid % a.nsplit;
     bid /= a.nsplit;
     const int tc = bid % ntc;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     const int p_end = min(a.npatch, p_begin + a.patches_per_block);
     if (p_begin >= p_end) {   // never taken with the host's split sizes, but a slab must not stay unwritten
         if (a.ws)
-            for (int v = 0; v < QT * 7; ++v) *(f32x4*)(a.ws + ((int64_t)blockIdx.x * QT * 7 * 256 + v * 256 + threadIdx.x) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < QT * 7; ++v) *(f32x4*)(a.ws + ((int64_t)lbid * QT * 7 * 256 + v * 256 + threadIdx.x) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
 
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
 
     // acc[i][n][r] = D[q = q0 + i*16 + 4*g16 + r][tap, c = c0 + j*16 + li]
     if (a.ws) {   // split-K partial in register layout (see wgrad.hip, wg_reduce_kernel<1>)
-        float* slab = a.ws + (int64_t)blockIdx.x * (QT * 7 * 256 * 4);
+        float* slab = a.ws + (int64_t)lbid * (QT * 7 * 256 * 4);
 #pragma unroll
         for (int n = 0; n < 7; ++n) {
             if (n >= nct) continue;
@@ -262,6 +264,7 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_by
         return AAU_E_INVALID;
     }
     a.ws = ws;
+    a.rev = next_traversal();
     hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR>), dim3((unsigned)grid), dim3(256), 0, s, a);
     if (!ws) return check_launch("aau_conv_wgrad(3x3)");
     WRedArgs r;

@@ -28,8 +28,11 @@ import torch.nn as nn
 from . import _abi, ops
 from ._abi import ConvDesc, PackEntry, STAT_REPLICAS
 
+import os as _os
+
 BF16 = torch.bfloat16
 F32 = torch.float32
+_NO_TRAVERSE = _os.environ.get("AAU_NO_TRAVERSE", "0") == "1"   # experiment switch
 ALIGN = 64  # elements; keeps every parameter 256-byte aligned inside the flat buffers
 
 
@@ -93,6 +96,16 @@ class _Rec:
         self.ops.append((None, None, "join", 0))
 
     def run(self, stream: int):
+        # alternate the traversal direction of the streaming kernels (aau_traverse): a consumer that starts where
+        # its producer finished finds that end of a > 128 MB tensor still in the 256-MiB Infinity Cache
+        trav = _abi.fn("aau_traverse")
+        trav(0 if _NO_TRAVERSE else 1)
+        try:
+            self._run(stream)
+        finally:
+            trav(0)
+
+    def _run(self, stream: int):
         side_t = side = None
         if self.uses_side:
             if self.side is None:

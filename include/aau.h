@@ -114,6 +114,16 @@ int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    float* dw, float* ws, int64_t ws_bytes, void* stream);
 int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes);
 
+/* Traversal hint (per calling thread).  alternate = 1: from now on every launch of the large  */
+/* streaming kernels (BN / pool / first and last layer / 3x3 and 1x1 convs / weight grads)    */
+/* walks its tensors in the direction OPPOSITE to the previous such launch, starting with     */
+/* "forward"; alternate = 0 (default): always forward.  Results do not depend on it.  Why:    */
+/* a consumer that starts where its producer just finished finds that end of a > 128 MB       */
+/* tensor still in the 256-MiB Infinity Cache (BN backward reduce -> apply at 201 MB tensors: */
+/* -12 % for the pair).  The engine calls it at the start of every forward / backward replay  */
+/* so that the directions are the same in every step.                                         */
+int aau_traverse(int alternate);
+
 /* ---- first layer: Conv2d(1, C, 3, pad 1) on fp32 input (pipeline:113 d1[0]) --------- */
 int aau_conv1_fwd(const float* x, const float* w /*[C][9]*/, aau_bf16* z, float* stats,
                   int N, int H, int W, int C, void* stream);

@@ -51,3 +51,10 @@ for name, Mg, Fi in (("u2", 8 * 256 * 256, 48), ("u3", 8 * 128 * 128, 96), ("u4"
     t = timeit(lambda: ops.gate_bwd2(*args))
     gb = (Mg * Fi * 2 * 3 + Mg * 8) / 1e9
     print(f"gate_bwd2 {name}: {t:.1f} us  ({gb / t * 1e3:.2f} TB/s)")
+
+# ---- reduce -> apply pair at level-1 size (Infinity Cache residency experiment: AAU_REV_APPLY=1) ----
+red.zero_()
+def pair():
+    ops.bn_bwd_reduce(z, C, dy, C, None, 0, None, C, scale, shift, mean, invstd, red, N, H, W, C, relu=1)
+    ops.bn_bwd_apply(z, C, dz, C, gamma, mean, invstd, red, dg, db, M, C, dy=dy, dyp=C, scale=scale, shift=shift, relu=1)
+print(f"reduce+apply pair: {timeit(pair):.1f} us")

@@ -385,3 +385,44 @@ def test_pack_weights_table(ops):
     exp4 = torch.zeros(16, 4, 32); exp4[:, :, :8] = wt.permute(0, 2, 3, 1).reshape(16, 4, 8)
     for off, n, exp in ((o1, n1, exp1), (o2, n2, exp2), (o3, n3, exp3), (o4, n4, exp4)):
         assert torch.equal(pk[off:off + n], R.bf16_round(exp).reshape(-1))
+
+
+def test_traversal_hint_does_not_change_results(ops):
+    """aau_traverse(1): launches alternate the direction in which they walk their tensors (Infinity-Cache hint);
+    outputs must be identical to the default direction."""
+    from att_aspp_unet_amd import _abi
+    N, H, W, C = 2, 32, 32, 48
+    g = torch.Generator().manual_seed(77)
+    z = dev(bf(torch.randn(N, H, W, C, generator=g)))
+    x = dev(bf(torch.randn(N, H, W, C, generator=g)))
+    w = R.bf16_round(torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5)
+    scale, shift = dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g) * 0.2)
+    cpad = ops.cpad_of(C)
+    wp = torch.zeros(C, 9, cpad)
+    wp[:, :, :C] = w.permute(0, 2, 3, 1).reshape(C, 9, C)
+    wp = dev(wp.to(torch.bfloat16))
+    d = ops.conv_desc(N, H, W, C, C, H, W, C, C, 3, 3, 1, 1, 1, cpad)
+
+    def run():
+        y = zeros(N, H, W, C, dtype=torch.bfloat16)
+        p = zeros(N, H // 2, W // 2, C, dtype=torch.bfloat16)
+        out = zeros(N, H, W, C, dtype=torch.bfloat16)
+        dw = zeros(C, 9, C)
+        ws = torch.empty(ops.conv_wgrad_ws_bytes(d) // 4, device="cuda")
+        for _ in range(2):                         # both directions of every kernel are exercised
+            ops.bn_act(z, C, y, C, scale, shift, N * H * W, C, relu=1)
+            ops.bn_act_pool(z, C, y, C, p, C, scale, shift, N, H, W, C)
+            ops.conv_igemm(d, x, wp, out)
+            dw.zero_()
+            ops.conv_wgrad(d, x, z, dw, ws)
+        torch.cuda.synchronize()
+        return y.clone(), p.clone(), out.clone(), dw.clone()
+
+    ref = run()
+    _abi.fn("aau_traverse")(1)
+    try:
+        got = run()
+    finally:
+        _abi.fn("aau_traverse")(0)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
