@@ -76,6 +76,7 @@ _SIGS = {
     "aau_outconv_fwd": [P, I, P, P, P, L, I, P],
     "aau_outconv_bwd": [P, I, P, P, P, I, P, P, P, L, I, P],
     "aau_colsum": [P, I, P, P, L, I, P],
+    "aau_fold_replicas": [P, I, P, I, P],
     "aau_criterion": [P, P, P, P, P, I, I, I, I, F, F, F, P],
     "aau_seg_metrics": [P, P, P, P, I, I, I, F, P],
     "aau_grad_sqnorm": [P, L, F, P, P],

@@ -522,3 +522,13 @@ extern "C" int aau_window_blend(const float* win_logits, float* out, int H, int 
                        out, H, W, win, stride, ny, nx, 1.0f / (2.f * sigma * sigma));
     return check_launch("aau_window_blend");
 }
+
+// out[i] += sum over the AAU_STAT_REPLICAS replicas of ws[r * stride + i], i < n.  Used to read a per-channel sum out of
+// the statistics a conv epilogue accumulated (e.g. the ConvTranspose2d bias gradient = column sums of the gradient
+// the preceding data-gradient conv produced: no separate pass over that tensor).
+extern "C" int aau_fold_replicas(const float* ws, int stride, float* out, int n, void* stream) {
+    AAU_REQUIRE(ws && out && n > 0 && stride >= n, "aau_fold_replicas: bad args");
+    hipLaunchKernelGGL(aau::fold_replicas_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, stride, out, n,
+                       (float*)nullptr);
+    return aau::check_launch("aau_fold_replicas");
+}

@@ -296,7 +296,7 @@ class Plan:
         st = eng.store
         nbn = st.bn_channels + 8
         self.stats_arena = _Arena(STAT_REPLICAS * 2 * nbn, self.dev)
-        self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3 + STAT_REPLICAS * nbn, self.dev)
+        self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3 + STAT_REPLICAS * nbn * 3, self.dev)
         self.vec_arena = _Arena(nbn * 8 + 64, self.dev)
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
         self.logits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
@@ -359,7 +359,7 @@ class Plan:
         return rec
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
-    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, feeds=None):
+    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, feeds=None, din_stats=None):
         """``feeds``: record of the ConvBNReLU whose output is this layer's ONLY consumer input (din is its full
         output gradient): its BatchNorm-backward reduce is then fused into this layer's data-gradient epilogue."""
         cv, bn, w = r["cv"], r["bn"], r["w"]
@@ -404,7 +404,8 @@ class Plan:
                       fw["mean"], fw["invstd"], fw["red"])
                 feeds["reduced_by_consumer"] = True
             else:
-                b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, None)
+                # din_stats: [R][2][Cin] sums of the produced gradient (channel sums feed the ConvTranspose bias grad)
+                b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, din_stats)
         return dz
 
     # ---- graph ----
@@ -537,7 +538,9 @@ class Plan:
             dya = self.new(Mo, Co)
             self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co, feeds=blk["ra"])
             dcat = self.new(Mo, 2 * Co)
-            self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=2 * Co)
+            # channel sums of dcat (fp32, from the data-gradient epilogue) -> ConvTranspose2d bias gradient below
+            sA = None if eng.no_fuse_colsum else self.red_arena.take(STAT_REPLICAS * 2 * 2 * Co)
+            self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=2 * Co, din_stats=sA)
             if lv == 0:
                 dcat1 = dcat
             cat, gt, up = blk["cat"], blk["gate"], blk["up"]
@@ -562,14 +565,20 @@ class Plan:
                     b.fork()
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], dzg, wg.dw, side=ov)
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], dzx, wx.dw, side=ov)
+                sB = None if sA is None else self.red_arena.take(STAT_REPLICAS * 2 * Co)
                 b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, 2 * Co, Cpad=wg.cpad_d,
                                                       accumulate=1), dzg, wg.pk_d, dcat[:, Co:], None, None, None,
-                      None)
+                      sB)
                 b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, Co, Cpad=wx.cpad_d,
                                                       accumulate=1), dzx, wx.pk_d, dskip[lv], None, None, None, None)
             # ConvTranspose2d backward: bias, weight, input
             gsrc, gc = blk["g_in"], blk["g_c"]
-            b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, rep_ws, Mo, Co)
+            if sA is None:
+                b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, rep_ws, Mo, Co)
+            else:
+                b.add("aau_fold_replicas", sA[Co:], 2 * 2 * Co, up.dbias, Co)
+                if gt is not None:
+                    b.add("aau_fold_replicas", sB, 2 * Co, up.dbias, Co)
             ov = eng.overlap_wgrad
             if ov:
                 b.fork()        # dcat[:, Co:] is final (gate data-gradient accumulated above)
@@ -654,6 +663,7 @@ class Engine:
         import os
         self.overlap_wgrad = os.environ.get("AAU_OVERLAP_WGRAD", "0") == "1"   # measured null on MI355X (A/B, same device)
         self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switches
+        self.no_fuse_colsum = os.environ.get("AAU_NO_FUSE_COLSUM", "0") == "1"
         # BN-backward reduce inside the consumer's data-gradient epilogue (aau_conv_igemm_bnred): measured a wash
         # (elementwise -0.41 ms, conv +0.43 ms per step: the epilogue's extra z read is not hidden), so opt-in
         self.no_fuse_bnred = os.environ.get("AAU_FUSE_BNRED", "0") != "1"

@@ -183,6 +183,10 @@ def outconv_bwd(y, yp, dlogits, w, dy, dyp, dw, db, ws, M, Cc):
                                 _stream()), "aau_outconv_bwd")
 
 
+def fold_replicas(ws, stride, out, n):
+    check(fn("aau_fold_replicas")(_p(ws), stride, _p(out), n, _stream()), "aau_fold_replicas")
+
+
 def colsum(src, sp, out, ws, M, Cc):
     check(fn("aau_colsum")(_p(src), sp, _p(out), _p(ws), M, Cc, _stream()), "aau_colsum")
 

@@ -253,6 +253,10 @@ int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlogits, const 
 /* out[c] += per-channel sum over pixels of a bf16 tensor (ConvTranspose2d bias gradient);   */
 /* ws as above                                                                              */
 int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float* ws, int64_t M, int C, void* stream);
+/* out[i] += sum_r ws[r*stride + i] (i < n, r < AAU_STAT_REPLICAS): reads a per-channel sum out  */
+/* of the `stats` a conv epilogue accumulated -- the ConvTranspose2d bias gradient is the        */
+/* channel sum of the gradient that the preceding data-gradient convs produced.                 */
+int aau_fold_replicas(const float* ws, int stride, float* out, int n, void* stream);
 
 /* ---- criterion (pipeline:219-232 build_criterion with ComboLoss :187-189, DiceLoss        */
 /* :173-178, EdgeLoss :196-216) and metrics (:191-194 iou_score, :240 eval Dice) -------- */
