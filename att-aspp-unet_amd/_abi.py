@@ -77,6 +77,9 @@ _SIGS = {
     "aau_outconv_bwd": [P, I, P, P, P, I, P, P, P, L, I, P],
     "aau_colsum": [P, I, P, P, L, I, P],
     "aau_fold_replicas": [P, I, P, I, P],
+    "aau_bn_act_outconv": [P, I, P, P, P, P, P, L, I, P],
+    "aau_bn_bwd_reduce_outconv": [P, I, P, P, P, P, P, P, P, P, P, P, L, I, P],
+    "aau_bn_bwd_apply_rank1": [P, I, P, I, P, P, P, P, P, P, L, I, P, P, P, P, P],
     "aau_criterion": [P, P, P, P, P, I, I, I, I, F, F, F, P],
     "aau_seg_metrics": [P, P, P, P, I, I, I, F, P],
     "aau_grad_sqnorm": [P, L, F, P, P],

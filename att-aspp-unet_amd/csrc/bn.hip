@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
                                                            const float* red, float* dgamma, float* dbeta, int64_t M,
                                                            int C, const unsigned short* dy, int dyp, const float* scale,
                                                            const float* shift, int relu, float drop_p, uint64_t seed,
-                                                           int64_t ppb) {
+                                                           const float* dl, const float* wout, int64_t ppb) {
     extern __shared__ float sm[];   // [2][C] replica sums, computed once per workgroup
     for (int cc = threadIdx.x; cc < C; cc += 256) {
         float a = 0.f, b = 0.f;
@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     float k0[8], k1[8], k2[8], mu[8], is[8], sc[8], sh[8];
     ldf8(mean + c, mu);
     ldf8(invstd + c, is);
-    if (dy) { ldf8(scale + c, sc); ldf8(shift + c, sh); }
+    // dl != null: the incoming gradient is rank one, dy[m][c] = bf16(dl[m] * wout[c]) (network head, never stored)
+    float wv[8];
+    if (dy || dl) { ldf8(scale + c, sc); ldf8(shift + c, sh); }
+    if (dl) ldf8(wout + c, wv);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         k0[j] = gamma[c + j] * is[j];
@@ -318,8 +321,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
         float zz[8], g[8];
         unpack8(ld16(z + m * zp + c), zz);
-        if (dy) {
-            unpack8(ld16(dy + m * dyp + c), g);
+        if (dy || dl) {
+            if (dy) {
+                unpack8(ld16(dy + m * dyp + c), g);
+            } else {
+                const float gl = dl[m];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = bf2f(f2bf(gl * wv[j]));
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float gv = g[j];
@@ -609,8 +618,26 @@ extern "C" int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, in
     if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, z, z_pitch, dz,
                        dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, M, C, dy, dy_pitch, scale, shift,
-                       relu, drop_p, drop_seed, ppb);
+                       relu, drop_p, drop_seed, (const float*)nullptr, (const float*)nullptr, ppb);
     return check_launch("aau_bn_bwd_apply");
+}
+
+extern "C" int aau_bn_bwd_apply_rank1(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch, const float* gamma,
+                                      const float* save_mean, const float* save_invstd, const float* red, float* dgamma,
+                                      float* dbeta, int64_t M, int C, const float* dlogits, const float* w_out,
+                                      const float* scale, const float* shift, void* stream) {
+    AAU_REQUIRE(z && dz && gamma && save_mean && save_invstd && red && dlogits && w_out && scale && shift && M > 0,
+                "aau_bn_bwd_apply_rank1: bad args");
+    CHK_C("aau_bn_bwd_apply_rank1", C);
+    AAU_REQUIRE(z_pitch % 8 == 0 && dz_pitch % 8 == 0, "aau_bn_bwd_apply_rank1: pitches must be multiples of 8");
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    int64_t blocks, ppb;
+    rows_split(M, CGMap(C).PL, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, z, z_pitch, dz,
+                       dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, M, C, (const unsigned short*)nullptr, 0,
+                       scale, shift, 1, 0.f, (uint64_t)0, dlogits, w_out, ppb);
+    return check_launch("aau_bn_bwd_apply_rank1");
 }
 
 extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const float* gamma, const float* save_mean,

@@ -192,6 +192,92 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const unsigned short* 
     if (tid == 0) atomicAdd(r + C, sb[0]);
 }
 
+// ---- network head, training forward: logits = out_conv(relu(bn(z))) in one pass (pipeline:121-122,126) ----
+// The activated tensor of the last ConvBNReLU is consumed by out_conv only, so it is never written: one thread per
+// pixel walks the channels in order, y is rounded to bf16 exactly as bn_act would store it and accumulated in the
+// order outconv_fwd uses (bitwise the same logits).
+__global__ __launch_bounds__(256) void bn_act_outconv_kernel(const unsigned short* z, int zp, const float* scale,
+                                                             const float* shift, const float* w, const float* b,
+                                                             float* logits, int64_t M, int C, int rev) {
+    extern __shared__ float sm[];   // [3][C]: scale, shift, w
+    for (int i = threadIdx.x; i < C; i += 256) { sm[i] = scale[i]; sm[C + i] = shift[i]; sm[2 * C + i] = w[i]; }
+    __syncthreads();
+    const float bias = b ? b[0] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = rev ? M - 1 - i : i;
+        float acc = bias;
+        for (int c = 0; c < C; c += 8) {
+            float f[8];
+            unpack8(*(const u32x4*)(z + m * zp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = bf2f(f2bf(fmaxf(f[j] * sm[c + j] + sm[C + c + j], 0.f)));
+                acc += y * sm[2 * C + c + j];
+            }
+        }
+        logits[m] = acc;
+    }
+}
+
+// ---- network head, backward: the gradient w.r.t. the last activation is rank one (dlogits[m] * w[c]), so it is
+// never materialised either.  This pass = outconv_bwd (dw += sum dl*y, db += sum dl, y recomputed from z) +
+// bn_bwd_reduce of the last BatchNorm (g = [y>0] * bf16(dl*w), sums of g and g*zhat).  ws: [R][C+8] replicas of
+// (dw, db), zeroed by the caller of the kernel; red: [R][2][C].
+__global__ __launch_bounds__(256) void bn_bwd_reduce_outconv_kernel(const unsigned short* z, int zp, const float* dl,
+                                                                    const float* w, const float* scale,
+                                                                    const float* shift, const float* mean,
+                                                                    const float* invstd, float* red, float* ws,
+                                                                    int64_t M, int C, int64_t ppb) {
+    __shared__ float sred[256 * 8];
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float s1[8], s2[8], sw[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = sw[j] = sb[j] = 0.f;
+    if (tid < mp.T) {
+        float wv[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wv[j] = w[c + j]; sc[j] = scale[c + j]; sh[j] = shift[c + j]; mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+        const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+            const float g = dl[m];
+            float f[8];
+            unpack8(*(const u32x4*)(z + m * zp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = f[j] * sc[j] + sh[j];
+                const float y = bf2f(f2bf(fmaxf(t, 0.f)));
+                sw[j] += g * y;
+                const float gv = t > 0.f ? bf2f(f2bf(g * wv[j])) : 0.f;   // the stored form of dy is bf16
+                s1[j] += gv;
+                s2[j] += gv * ((f[j] - mu[j]) * is[j]);
+            }
+            if (cg == 0) sb[0] += g;
+        }
+    }
+    const int rep = blockIdx.x % AAU_STAT_REPLICAS;
+    float* r = red + (size_t)rep * 2 * C;
+    float* ro = ws + (size_t)rep * (C + 8);
+    block_sum8b(s1, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s1[j]);
+    }
+    block_sum8b(s2, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
+    }
+    block_sum8b(sw, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(ro + c + j, sw[j]);
+    }
+    block_sum8b(sb, sred, mp, tid);
+    if (tid == 0) atomicAdd(ro + C, sb[0]);
+}
+
 // out[i] += sum over replicas of ws[r][i] (i < n); optionally a second target for element n (bias)
 __global__ void fold_replicas_kernel(const float* ws, int stride, float* out, int n, float* out2) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -531,4 +617,36 @@ extern "C" int aau_fold_replicas(const float* ws, int stride, float* out, int n,
     hipLaunchKernelGGL(aau::fold_replicas_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, stride, out, n,
                        (float*)nullptr);
     return aau::check_launch("aau_fold_replicas");
+}
+
+extern "C" int aau_bn_act_outconv(const aau_bf16* z, int z_pitch, const float* scale, const float* shift, const float* w,
+                                  const float* b, float* logits, int64_t M, int C, void* stream) {
+    AAU_REQUIRE(z && scale && shift && w && logits && M > 0, "aau_bn_act_outconv: bad args");
+    CHK_C("aau_bn_act_outconv", C);
+    AAU_REQUIRE(z_pitch % 8 == 0, "aau_bn_act_outconv: pitch");
+    ProfScope prof(2, 4.0 * M * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_act_outconv_kernel, dim3(grid1d(M)), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream, z,
+                       z_pitch, scale, shift, w, b, logits, M, C, next_traversal());
+    return check_launch("aau_bn_act_outconv");
+}
+
+extern "C" int aau_bn_bwd_reduce_outconv(const aau_bf16* z, int z_pitch, const float* dlogits, const float* w,
+                                         const float* scale, const float* shift, const float* save_mean,
+                                         const float* save_invstd, float* red, float* dw, float* db, float* ws, int64_t M,
+                                         int C, void* stream) {
+    AAU_REQUIRE(z && dlogits && w && scale && shift && save_mean && save_invstd && red && dw && ws && M > 0,
+                "aau_bn_bwd_reduce_outconv: bad args");
+    CHK_C("aau_bn_bwd_reduce_outconv", C);
+    AAU_REQUIRE(z_pitch % 8 == 0, "aau_bn_bwd_reduce_outconv: pitch");
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows(M, mp.PL, 16, 2048, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
+    ProfScope prof(2, 8.0 * M * C, (hipStream_t)stream);
+    zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * (C + 8), (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_bwd_reduce_outconv_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, z_pitch,
+                       dlogits, w, scale, shift, save_mean, save_invstd, red, ws, M, C, ppb);
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, dw, C,
+                       db);
+    return check_launch("aau_bn_bwd_reduce_outconv");
 }

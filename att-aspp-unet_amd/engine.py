@@ -323,8 +323,10 @@ class Plan:
         self.fwd.add("aau_bn_fold_eval", bn.gamma, bn.beta, bn.rm, bn.rv, w["scale"], w["shift"], bn.C, 1e-5)
 
     # ---- ConvBNReLU on MFMA: forward ----
-    def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0, pool=None):
-        """conv(cname) -> BN(bname) -> ReLU; returns the per-layer record used by the backward."""
+    def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0, pool=None, head=None):
+        """conv(cname) -> BN(bname) -> ReLU; returns the per-layer record used by the backward.
+        ``head`` (training only): the out_conv ConvP when this is the last ConvBNReLU -- its activation feeds out_conv
+        alone, so BN + ReLU + out_conv run as one pass and neither the activation nor its gradient is stored."""
         st = self.eng.store
         cv, bn = st.convs[cname], st.bns[bname]
         M = N * H * W
@@ -337,7 +339,10 @@ class Plan:
             self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
             self._bn_finalize(bn, w, M)
             Mo = M * bcast_hw if bcast_hw else M
-            if pool is not None:
+            if head is not None:
+                self.fwd.add("aau_bn_act_outconv", z, cv.O, w["scale"], w["shift"], head.w, head.bias, self.logits, M, cv.O)
+                rec["head"] = head
+            elif pool is not None:
                 self.fwd.add("aau_bn_act_pool", z, cv.O, ydst, yp, pool, cv.O, w["scale"], w["shift"], N, H, W, cv.O)
             else:
                 self.fwd.add("aau_bn_act", z, cv.O, ydst, yp, w["scale"], w["shift"], Mo, cv.O, 1, bcast_hw,
@@ -368,7 +373,14 @@ class Plan:
         dp_ = self.drop_p if r["drop"] else 0.0
         fuse1 = cv.kind == "first" and dpool is None and dp_ == 0.0 and not self.eng.no_fuse_conv1
         dz = None if fuse1 else self.new(M, cv.O)
-        if dpool is None:
+        head = r.get("head")
+        if head is not None:
+            # network head: dy = dlogits x w_out is rank one and never stored (see cbr_fwd)
+            b.add("aau_bn_bwd_reduce_outconv", r["z"], cv.O, self.dlogits, head.w, w["scale"], w["shift"], w["mean"],
+                  w["invstd"], w["red"], head.dw, head.dbias, self.rep_ws, M, cv.O)
+            b.add("aau_bn_bwd_apply_rank1", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
+                  bn.dbeta, M, cv.O, self.dlogits, head.w, w["scale"], w["shift"])
+        elif dpool is None:
             # no pooling: the reduce pass only accumulates, the apply pass recomputes the ReLU / dropout mask
             if not r.get("reduced_by_consumer", False):
                 b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"],
@@ -515,22 +527,28 @@ class Plan:
                             wrep=self.red_arena.take(STAT_REPLICAS * Fi) if tr else None)
             ya = self.new(Mo, Co)
             ra = self.cbr_fwd(f"{name}.conv.0.block.0", f"{name}.conv.0.block.1", cat, 2 * Co, B, ho, wo, ya, Co)
-            yb = self.new(Mo, Co)
-            rb = self.cbr_fwd(f"{name}.conv.1.block.0", f"{name}.conv.1.block.1", ya, Co, B, ho, wo, yb, Co)
+            fuse_head = tr and lv == 0 and not eng.no_fuse_head
+            yb = None if fuse_head else self.new(Mo, Co)
+            rb = self.cbr_fwd(f"{name}.conv.1.block.0", f"{name}.conv.1.block.1", ya, Co, B, ho, wo, yb, Co,
+                              head=st.convs["out_conv"] if fuse_head else None)
             dec.append(dict(lv=lv, name=name, up=up, cat=cat, gate=gate, ra=ra, rb=rb, g_in=g_in, g_c=g_c, Co=Co,
                             hi=hi, wi=wi, ho=ho, wo=wo, Mo=Mo, out=yb))
             g_in, g_c = yb, Co
         oc = st.convs["out_conv"]
-        f.add("aau_outconv_fwd", g_in, c, oc.w, oc.bias, self.logits, Ms[0], c)
+        fused_head = g_in is None
+        if not fused_head:
+            f.add("aau_outconv_fwd", g_in, c, oc.w, oc.bias, self.logits, Ms[0], c)
         if not tr:
             return
 
         # =============================== backward ===============================
         b = self.bwd
         mark = self._mark
-        dy = self.new(Ms[0], c)
         rep_ws = self.rep_ws = self.new(STAT_REPLICAS * (max(Cs) + 8), dtype=F32)   # replica scratch of the column reductions
-        b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, rep_ws, Ms[0], c)
+        dy = None
+        if not fused_head:
+            dy = self.new(Ms[0], c)
+            b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, rep_ws, Ms[0], c)
         dskip = [None, self.new(Ms[1], Cs[1]), self.new(Ms[2], Cs[2]), self.new(Ms[3], Cs[3])]
         dcat1 = None
         for blk in reversed(dec):            # u1, u2, u3, u4
@@ -664,6 +682,7 @@ class Engine:
         self.overlap_wgrad = os.environ.get("AAU_OVERLAP_WGRAD", "0") == "1"   # measured null on MI355X (A/B, same device)
         self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switches
         self.no_fuse_colsum = os.environ.get("AAU_NO_FUSE_COLSUM", "0") == "1"
+        self.no_fuse_head = os.environ.get("AAU_NO_FUSE_HEAD", "0") == "1"
         # BN-backward reduce inside the consumer's data-gradient epilogue (aau_conv_igemm_bnred): measured a wash
         # (elementwise -0.41 ms, conv +0.43 ms per step: the epilogue's extra z read is not hidden), so opt-in
         self.no_fuse_bnred = os.environ.get("AAU_FUSE_BNRED", "0") != "1"

@@ -183,6 +183,22 @@ def outconv_bwd(y, yp, dlogits, w, dy, dyp, dw, db, ws, M, Cc):
                                 _stream()), "aau_outconv_bwd")
 
 
+def bn_act_outconv(z, zp, scale, shift, w, b, logits, M, Cc):
+    check(fn("aau_bn_act_outconv")(_p(z), zp, _p(scale), _p(shift), _p(w), _p(b), _p(logits), M, Cc, _stream()),
+          "aau_bn_act_outconv")
+
+
+def bn_bwd_reduce_outconv(z, zp, dlogits, w, scale, shift, smean, sinvstd, red, dw, db, ws, M, Cc):
+    check(fn("aau_bn_bwd_reduce_outconv")(_p(z), zp, _p(dlogits), _p(w), _p(scale), _p(shift), _p(smean), _p(sinvstd),
+                                          _p(red), _p(dw), _p(db), _p(ws), M, Cc, _stream()), "aau_bn_bwd_reduce_outconv")
+
+
+def bn_bwd_apply_rank1(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, Cc, dlogits, w_out, scale, shift):
+    check(fn("aau_bn_bwd_apply_rank1")(_p(z), zp, _p(dz), dzp, _p(gamma), _p(smean), _p(sinvstd), _p(red), _p(dgamma),
+                                       _p(dbeta), M, Cc, _p(dlogits), _p(w_out), _p(scale), _p(shift), _stream()),
+          "aau_bn_bwd_apply_rank1")
+
+
 def fold_replicas(ws, stride, out, n):
     check(fn("aau_fold_replicas")(_p(ws), stride, _p(out), n, _stream()), "aau_fold_replicas")
 

@@ -250,6 +250,25 @@ int aau_outconv_fwd(const aau_bf16* y, int y_pitch, const float* w, const float*
 int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlogits, const float* w,
                     aau_bf16* dy, int dy_pitch, float* dw, float* db, float* ws, int64_t M, int C,
                     void* stream);
+/* Network head in training (pipeline:121-122,126: the last ConvBNReLU feeds out_conv only).    */
+/* forward: logits[m] = b + sum_c w[c] * bf16(relu(z[m][c]*scale[c]+shift[c])) -- the activated   */
+/* tensor is never written (bitwise the logits of aau_bn_act + aau_outconv_fwd).                 */
+int aau_bn_act_outconv(const aau_bf16* z, int z_pitch, const float* scale, const float* shift,
+                       const float* w, const float* b, float* logits, int64_t M, int C, void* stream);
+/* backward: the gradient w.r.t. that activation is rank one, dy[m][c] = bf16(dlogits[m]*w[c]),   */
+/* and is never written either.  reduce_outconv = aau_outconv_bwd's parameter gradients           */
+/* (dw[c] += sum dl*y, db += sum dl; y recomputed from z) + aau_bn_bwd_reduce of the last         */
+/* BatchNorm; ws: fp32 [AAU_STAT_REPLICAS][C+8] scratch.  apply_rank1 = aau_bn_bwd_apply with     */
+/* that dy.                                                                                      */
+int aau_bn_bwd_reduce_outconv(const aau_bf16* z, int z_pitch, const float* dlogits, const float* w,
+                              const float* scale, const float* shift, const float* save_mean,
+                              const float* save_invstd, float* red, float* dw, float* db, float* ws,
+                              int64_t M, int C, void* stream);
+int aau_bn_bwd_apply_rank1(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
+                           const float* gamma, const float* save_mean, const float* save_invstd,
+                           const float* red, float* dgamma, float* dbeta, int64_t M, int C,
+                           const float* dlogits, const float* w_out, const float* scale,
+                           const float* shift, void* stream);
 /* out[c] += per-channel sum over pixels of a bf16 tensor (ConvTranspose2d bias gradient);   */
 /* ws as above                                                                              */
 int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float* ws, int64_t M, int C, void* stream);

@@ -426,3 +426,47 @@ def test_traversal_hint_does_not_change_results(ops):
         _abi.fn("aau_traverse")(0)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C", [48, 8, 104])
+def test_network_head_fused_forward_and_backward(ops, C):
+    """aau_bn_act_outconv / aau_bn_bwd_reduce_outconv / aau_bn_bwd_apply_rank1 against the unfused chain
+    bn_act -> outconv_fwd and outconv_bwd -> bn_bwd_reduce -> bn_bwd_apply (pipeline:121-122,126)."""
+    M = 2 * 24 * 40
+    g = torch.Generator().manual_seed(200 + C)
+    z = dev(bf(torch.randn(M, C, generator=g)))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    zf = z.float().cpu()
+    mean, var = zf.mean(0), zf.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    scale, shift = dev(gamma * invstd), dev(beta - mean * gamma * invstd)
+    w, b = dev(torch.randn(C, generator=g) * 0.3), dev(torch.randn(1, generator=g))
+    dl = dev(torch.randn(M, generator=g))
+    # unfused
+    y = zeros(M, C, dtype=torch.bfloat16)
+    ops.bn_act(z, C, y, C, scale, shift, M, C, relu=1)
+    lg0 = zeros(M)
+    ops.outconv_fwd(y, C, w, b, lg0, M, C)
+    dy = zeros(M, C, dtype=torch.bfloat16)
+    dw0, db0 = zeros(C), zeros(1)
+    ws = torch.full((ops.STAT_REPLICAS * (C + 8),), float("nan"), device="cuda")
+    ops.outconv_bwd(y, C, dl, w, dy, C, dw0, db0, ws, M, C)
+    red0 = zeros(ops.STAT_REPLICAS, 2, C)
+    ops.bn_bwd_reduce(z, C, dy, C, None, 0, None, C, scale, shift, dev(mean), dev(invstd), red0, 1, 1, M, C, relu=1)
+    dz0, dg0, dbt0 = zeros(M, C, dtype=torch.bfloat16), zeros(C), zeros(C)
+    ops.bn_bwd_apply(z, C, dz0, C, dev(gamma), dev(mean), dev(invstd), red0, dg0, dbt0, M, C, dy=dy, dyp=C, scale=scale,
+                     shift=shift, relu=1)
+    # fused
+    lg1 = zeros(M)
+    ops.bn_act_outconv(z, C, scale, shift, w, b, lg1, M, C)
+    red1, dw1, db1 = zeros(ops.STAT_REPLICAS, 2, C), zeros(C), zeros(1)
+    ws.fill_(float("nan"))
+    ops.bn_bwd_reduce_outconv(z, C, dl, w, scale, shift, dev(mean), dev(invstd), red1, dw1, db1, ws, M, C)
+    dz1, dg1, dbt1 = zeros(M, C, dtype=torch.bfloat16), zeros(C), zeros(C)
+    ops.bn_bwd_apply_rank1(z, C, dz1, C, dev(gamma), dev(mean), dev(invstd), red1, dg1, dbt1, M, C, dl, w, scale, shift)
+    torch.cuda.synchronize()
+    assert torch.equal(lg1, lg0)
+    assert rel_err(dw1.cpu(), dw0.cpu()) < 1e-5 and rel_err(db1.cpu(), db0.cpu()) < 1e-5
+    assert rel_err(red1.sum(0).cpu(), red0.sum(0).cpu()) < 1e-5
+    assert rel_err(dg1.cpu(), dg0.cpu()) < 1e-5 and rel_err(dbt1.cpu(), dbt0.cpu()) < 1e-5
+    assert rel_err(dz1.cpu(), dz0.cpu()) < 1e-2 and float((dz1.float() != dz0.float()).float().mean()) < 1e-2
