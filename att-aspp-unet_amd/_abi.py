@@ -64,7 +64,9 @@ _SIGS = {
     "aau_maxpool2": [P, I, P, I, I, I, I, I, P],
     "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, U64, P],
     "aau_bn_bwd_apply": [P, I, P, I, P, P, P, P, P, P, L, I, P, I, P, P, I, F, U64, P],
-    "aau_bn_bwd_apply_conv1": [P, I, P, P, P, P, P, P, I, I, I, I, P, I, P, P, P, P, P, P],
+    "aau_bn_bwd_apply_conv1": [P, I, P, P, P, P, P, P, I, I, I, I, P, I, P, P, P, P, P, P, P],
+    "aau_conv1_bn_act": [P, P, P, I, P, P, I, I, I, I, P],
+    "aau_conv1_bn_bwd_reduce": [P, P, P, I, P, P, P, P, P, I, I, I, I, P],
     "aau_gap_fwd": [P, I, P, P, I, I, I, P],
     "aau_gap_bwd": [P, P, I, I, I, I, P],
     "aau_spatial_sum": [P, I, P, P, I, I, I, P],

@@ -357,9 +357,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
                                                                  const float* red, float* dgamma, float* dbeta, int M,
                                                                  int C, const unsigned short* dy, int dyp,
                                                                  const float* scale, const float* shift,
-                                                                 const float* x, int H, int W, float* ws, int ppb) {
-    extern __shared__ float sm[];   // [2][C] replica sums, then [C*9] workgroup accumulators
+                                                                 const float* x, int H, int W, float* ws,
+                                                                 const float* wconv, int ppb) {
+    extern __shared__ float sm[];   // [2][C] replica sums, [C*9] workgroup accumulators, [C*9] conv weights (z == null)
     float* sacc = sm + 2 * C;
+    float* swc = sm + 11 * C;
+    if (!z)
+        for (int i = threadIdx.x; i < C * 9; i += 256) swc[i] = wconv[i];
     for (int cc = threadIdx.x; cc < C; cc += 256) {
         float a = 0.f, b = 0.f;
         for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
@@ -410,17 +414,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
         const int stepx = PL4 % W, stepr = PL4 / W;
         auto load_px = [&](u32x2& zq, u32x2& gq, f32x2 v[5]) {
             const float* img = x + (int64_t)(row - yy) * W;
-            zq = *(const u32x2*)(z + (int64_t)m * zp + c);
             gq = *(const u32x2*)(dy + (int64_t)m * dyp + c);
             float t[10];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int y2 = yy + ky - 1, x2 = xx + kx - 1;
-                    t[ky * 3 + kx] = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) ? img[y2 * W + x2] : 0.f;
-                }
+            conv1_taps(img, yy, xx, H, W, t);
             t[9] = 0.f;
+            if (z) {
+                zq = *(const u32x2*)(z + (int64_t)m * zp + c);
+            } else {   // z of the first layer is not stored: the same fma chain as conv1_fwd gives the same bf16 bits
+                zq[0] = pack2(conv1_dot(t, swc + (c + 0) * 9), conv1_dot(t, swc + (c + 1) * 9));
+                zq[1] = pack2(conv1_dot(t, swc + (c + 2) * 9), conv1_dot(t, swc + (c + 3) * 9));
+            }
 #pragma unroll
             for (int k = 0; k < 5; ++k) v[k] = f32x2{t[2 * k], t[2 * k + 1]};
             // advance to this thread's next pixel
@@ -643,9 +646,11 @@ extern "C" int aau_bn_bwd_apply_rank1(const aau_bf16* z, int z_pitch, aau_bf16* 
 extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const float* gamma, const float* save_mean,
                                       const float* save_invstd, const float* red, float* dgamma, float* dbeta, int N,
                                       int H, int W, int C, const aau_bf16* dy, int dy_pitch, const float* scale,
-                                      const float* shift, const float* x, float* dw, float* ws, void* stream) {
-    AAU_REQUIRE(z && gamma && save_mean && save_invstd && red && dy && scale && shift && x && dw && ws && N > 0 && H > 0 &&
-                    W > 0, "aau_bn_bwd_apply_conv1: bad args");
+                                      const float* shift, const float* x, const float* w, float* dw, float* ws,
+                                      void* stream) {
+    AAU_REQUIRE((z || w) && gamma && save_mean && save_invstd && red && dy && scale && shift && x && dw && ws && N > 0 &&
+                    H > 0 && W > 0, "aau_bn_bwd_apply_conv1: bad args");
+    AAU_REQUIRE((int64_t)H * W < 0x7fffffff, "aau_bn_bwd_apply_conv1: image too large");
     CHK_C("aau_bn_bwd_apply_conv1", C);
     AAU_REQUIRE(z_pitch % 8 == 0 && dy_pitch % 8 == 0, "aau_bn_bwd_apply_conv1: pitches must be multiples of 8");
     const int64_t M = (int64_t)N * H * W;
@@ -656,9 +661,9 @@ extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const floa
     rows_split(M, 256 / (C >> 2), &blocks, &ppb);
     const int ppb_signed = next_traversal() ? -(int)ppb : (int)ppb;
     zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * C * 9, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel, dim3((unsigned)blocks), dim3(256), (2 * C + 9 * C) * sizeof(float),
+    hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel, dim3((unsigned)blocks), dim3(256), (2 * C + 9 * C + 9 * C) * sizeof(float),
                        (hipStream_t)stream, z, z_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, (int)M, C, dy,
-                       dy_pitch, scale, shift, x, H, W, ws, ppb_signed);
+                       dy_pitch, scale, shift, x, H, W, ws, w, ppb_signed);
     hipLaunchKernelGGL(fold_conv1_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9);
     return check_launch("aau_bn_bwd_apply_conv1");
 }

@@ -64,6 +64,25 @@ __device__ __forceinline__ float row16_sum(float x) {
     return x;
 }
 
+// One output value of the first layer, Conv2d(1, C, 3, pad 1): a FIXED fma chain over the 9 taps, so that every kernel
+// that recomputes z from the frame instead of reading it (the first layer's z is never stored) gets the same bits.
+__device__ __forceinline__ float conv1_dot(const float v[9], const float* w9) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc = __builtin_fmaf(v[k], w9[k], acc);
+    return acc;
+}
+// the 9 taps of pixel (yy, xx) of one fp32 image (zero padding)
+__device__ __forceinline__ void conv1_taps(const float* img, int yy, int xx, int H, int W, float v[9]) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+            v[ky * 3 + kx] = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W) ? img[y2 * W + x2] : 0.f;
+        }
+}
+
 // First row of this workgroup's slice of a row-split launch.  A NEGATIVE rows-per-block encodes "walk the tensor
 // from its end" (aau_traverse): workgroup b then owns slice gridDim.x-1-b.  Makes rpb positive.
 template <typename T>

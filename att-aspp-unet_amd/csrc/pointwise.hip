@@ -57,25 +57,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* x, const fl
             const int yy = (int)(t % H);
             const float* img = x + (t - yy) * W;  // start of image n
             float v[9];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int y2 = yy + ky - 1, x2 = xx + kx - 1;
-                    v[ky * 3 + kx] = ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
-                                         ? img[(int64_t)y2 * W + x2] : 0.f;
-                }
+            conv1_taps(img, yy, xx, H, W, v);
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) acc += v[k] * sw[(c + j) * 9 + k];
+                const float acc = conv1_dot(v, sw + (c + j) * 9);
                 o[j] = acc;
                 s1[j] += acc;
                 s2[j] += acc * acc;
             }
-            *(u32x4*)(z + m * C + c) = pack8(o);
+            if (z) *(u32x4*)(z + m * C + c) = pack8(o);   // z == null: statistics only, consumers recompute z
         }
     }
     if (stats) {
@@ -90,6 +81,88 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* x, const fl
 #pragma unroll
             for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
         }
+    }
+}
+
+// ---- first layer: y = relu(bn(conv1(x))) straight from the frame (z is recomputed, never read) ----
+__global__ __launch_bounds__(256) void conv1_bn_act_kernel(const float* x, const float* w, unsigned short* y, int yp,
+                                                           const float* scale, const float* shift, int N, int H, int W,
+                                                           int C, int64_t ppb) {
+    extern __shared__ float sw[];  // [C*9]
+    for (int i = threadIdx.x; i < C * 9; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    if (tid >= mp.T) return;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[c + j]; sh[j] = shift[c + j]; }
+    const int64_t M = (int64_t)N * H * W;
+    const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
+    for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+        const int xx = (int)(m % W);
+        const int64_t t = m / W;
+        const int yy = (int)(t % H);
+        float v[9], o[8];
+        conv1_taps(x + (t - yy) * W, yy, xx, H, W, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float zq = bf2f(f2bf(conv1_dot(v, sw + (c + j) * 9)));   // z as it would have been stored
+            o[j] = fmaxf(zq * sc[j] + sh[j], 0.f);
+        }
+        *(u32x4*)(y + m * yp + c) = pack8(o);
+    }
+}
+
+// ---- first layer: BatchNorm-backward reduce with z recomputed from the frame ----
+__global__ __launch_bounds__(256) void conv1_bn_bwd_reduce_kernel(const float* x, const float* w, const unsigned short* dy,
+                                                                  int dyp, const float* scale, const float* shift,
+                                                                  const float* mean, const float* invstd, float* red,
+                                                                  int N, int H, int W, int C, int64_t ppb) {
+    extern __shared__ float sm[];  // [C*9] weights, then [256*8] reduction scratch
+    float* sw = sm;
+    float* sred = sm + C * 9;
+    for (int i = threadIdx.x; i < C * 9; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const CGMap2 mp(C);
+    const int tid = threadIdx.x;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    if (tid < mp.T) {
+        float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = scale[c + j]; sh[j] = shift[c + j]; mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+        const int64_t M = (int64_t)N * H * W;
+        const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+            const int xx = (int)(m % W);
+            const int64_t t = m / W;
+            const int yy = (int)(t % H);
+            float v[9], g[8];
+            unpack8(*(const u32x4*)(dy + m * dyp + c), g);
+            conv1_taps(x + (t - yy) * W, yy, xx, H, W, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float zq = bf2f(f2bf(conv1_dot(v, sw + (c + j) * 9)));
+                const float gv = (zq * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;
+                s1[j] += gv;
+                s2[j] += gv * ((zq - mu[j]) * is[j]);
+            }
+        }
+    }
+    float* r = red + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * C;
+    block_sum8b(s1, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s1[j]);
+    }
+    block_sum8b(s2, sred, mp, tid);
+    if (tid < mp.CG) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
     }
 }
 
@@ -454,7 +527,7 @@ using namespace aau;
 
 extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, float* stats, int N, int H, int W, int C,
                              void* stream) {
-    AAU_REQUIRE(x && w && z && N > 0 && H > 0 && W > 0, "aau_conv1_fwd: bad args");
+    AAU_REQUIRE(x && w && (z || stats) && N > 0 && H > 0 && W > 0, "aau_conv1_fwd: bad args");
     CHK_C("aau_conv1_fwd", C);
     const CGMap2 mp(C);
     int64_t blocks, ppb;
@@ -649,4 +722,38 @@ extern "C" int aau_bn_bwd_reduce_outconv(const aau_bf16* z, int z_pitch, const f
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, dw, C,
                        db);
     return check_launch("aau_bn_bwd_reduce_outconv");
+}
+
+extern "C" int aau_conv1_bn_act(const float* x, const float* w, aau_bf16* y, int y_pitch, const float* scale,
+                                const float* shift, int N, int H, int W, int C, void* stream) {
+    AAU_REQUIRE(x && w && y && scale && shift && N > 0 && H > 0 && W > 0, "aau_conv1_bn_act: bad args");
+    CHK_C("aau_conv1_bn_act", C);
+    AAU_REQUIRE(y_pitch % 8 == 0, "aau_conv1_bn_act: pitch");
+    AAU_REQUIRE((int64_t)H * W < 0x7fffffff, "aau_conv1_bn_act: image too large");
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows((int64_t)N * H * W, mp.PL, 16, 4096, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
+    ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(conv1_bn_act_kernel, dim3((unsigned)blocks), dim3(256), C * 9 * sizeof(float), (hipStream_t)stream, x, w,
+                       y, y_pitch, scale, shift, N, H, W, C, ppb);
+    return check_launch("aau_conv1_bn_act");
+}
+
+extern "C" int aau_conv1_bn_bwd_reduce(const float* x, const float* w, const aau_bf16* dy, int dy_pitch,
+                                       const float* scale, const float* shift, const float* save_mean,
+                                       const float* save_invstd, float* red, int N, int H, int W, int C, void* stream) {
+    AAU_REQUIRE(x && w && dy && scale && shift && save_mean && save_invstd && red && N > 0 && H > 0 && W > 0,
+                "aau_conv1_bn_bwd_reduce: bad args");
+    CHK_C("aau_conv1_bn_bwd_reduce", C);
+    AAU_REQUIRE(dy_pitch % 8 == 0, "aau_conv1_bn_bwd_reduce: pitch");
+    AAU_REQUIRE((int64_t)H * W < 0x7fffffff, "aau_conv1_bn_bwd_reduce: image too large");
+    const CGMap2 mp(C);
+    int64_t blocks, ppb;
+    split_rows((int64_t)N * H * W, mp.PL, 32, 2048, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
+    ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(conv1_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (C * 9 + 256 * 8) * sizeof(float),
+                       (hipStream_t)stream, x, w, dy, dy_pitch, scale, shift, save_mean, save_invstd, red, N, H, W, C, ppb);
+    return check_launch("aau_conv1_bn_bwd_reduce");
 }

@@ -383,12 +383,16 @@ class Plan:
         elif dpool is None:
             # no pooling: the reduce pass only accumulates, the apply pass recomputes the ReLU / dropout mask
             if not r.get("reduced_by_consumer", False):
-                b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"],
-                      w["mean"], w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
+                if r["z"] is None:      # first layer, z not stored
+                    b.add("aau_conv1_bn_bwd_reduce", r["src"], cv.w, dy, dyp, w["scale"], w["shift"], w["mean"],
+                          w["invstd"], w["red"], N, H, W, cv.O)
+                else:
+                    b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"],
+                          w["mean"], w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
             if fuse1:
                 # first layer: no input gradient, so the apply pass feeds the weight gradient directly
                 b.add("aau_bn_bwd_apply_conv1", r["z"], cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
-                      bn.dbeta, N, H, W, cv.O, dy, dyp, w["scale"], w["shift"], r["src"], cv.dw, self.rep_ws)
+                      bn.dbeta, N, H, W, cv.O, dy, dyp, w["scale"], w["shift"], r["src"], cv.w, cv.dw, self.rep_ws)
                 return None
             b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
                   bn.dbeta, M, cv.O, dy, dyp, w["scale"], w["shift"], 1, dp_, self.drop_seed)
@@ -409,7 +413,8 @@ class Plan:
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate)
-            if (feeds is not None and not self.eng.no_fuse_bnred and not feeds["drop"] and dinp == feeds["cv"].O
+            if (feeds is not None and feeds["z"] is not None and not self.eng.no_fuse_bnred and not feeds["drop"]
+                    and dinp == feeds["cv"].O
                     and ops.conv_is_halo3x3(dd)):
                 fw = feeds["w"]
                 b.add("aau_conv_igemm_bnred", dd, dz, cv.pk_d, din, feeds["z"], feeds["cv"].O, fw["scale"], fw["shift"],
@@ -445,15 +450,25 @@ class Plan:
         w0 = self.bnbuf(c)
         y10 = self.new(Ms[0], c)
         r10 = dict(cv=cv0, bn=bn0, w=w0, N=B, H=H, W=W, M=Ms[0], src=self.x, sp=1, drop=False, bcast_hw=0)
-        z10 = self.new(Ms[0], c)
-        r10["z"] = z10
-        if tr:
-            f.add("aau_conv1_fwd", self.x, cv0.w, z10, w0["stats"], B, H, W, c)
-            self._bn_finalize(bn0, w0, Ms[0])
+        if eng.no_recompute_z1:
+            z10 = self.new(Ms[0], c)
+            f.add("aau_conv1_fwd", self.x, cv0.w, z10, w0["stats"] if tr else None, B, H, W, c)
+            if tr:
+                self._bn_finalize(bn0, w0, Ms[0])
+            else:
+                self._bn_fold(bn0, w0)
+            f.add("aau_bn_act", z10, c, y10, c, w0["scale"], w0["shift"], Ms[0], c, 1, 0, 0.0, self.drop_seed)
         else:
-            f.add("aau_conv1_fwd", self.x, cv0.w, z10, None, B, H, W, c)
-            self._bn_fold(bn0, w0)
-        f.add("aau_bn_act", z10, c, y10, c, w0["scale"], w0["shift"], Ms[0], c, 1, 0, 0.0, self.drop_seed)
+            # z of the first layer (9 FMAs per value) is never stored: statistics pass, then y straight from the frame;
+            # the backward recomputes it the same way (aau_conv1_bn_bwd_reduce, aau_bn_bwd_apply_conv1)
+            z10 = None
+            if tr:
+                f.add("aau_conv1_fwd", self.x, cv0.w, None, w0["stats"], B, H, W, c)
+                self._bn_finalize(bn0, w0, Ms[0])
+            else:
+                self._bn_fold(bn0, w0)
+            f.add("aau_conv1_bn_act", self.x, cv0.w, y10, c, w0["scale"], w0["shift"], B, H, W, c)
+        r10["z"] = z10
         r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, cat1, 2 * c, pool=pools[0])
         enc.append((r10, r11))
         for lv in range(1, 4):
@@ -683,6 +698,9 @@ class Engine:
         self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switches
         self.no_fuse_colsum = os.environ.get("AAU_NO_FUSE_COLSUM", "0") == "1"
         self.no_fuse_head = os.environ.get("AAU_NO_FUSE_HEAD", "0") == "1"
+        # z of the first layer recomputed from the frame instead of stored (-201 MB of HBM at bs 8 / 512^2): measured
+        # 0.08 ms SLOWER per step (the three recomputing kernels are VALU / latency bound, not byte bound), so opt-in
+        self.no_recompute_z1 = os.environ.get("AAU_RECOMPUTE_Z1", "0") != "1" or self.no_fuse_conv1
         # BN-backward reduce inside the consumer's data-gradient epilogue (aau_conv_igemm_bnred): measured a wash
         # (elementwise -0.41 ms, conv +0.43 ms per step: the epilogue's extra z read is not hidden), so opt-in
         self.no_fuse_bnred = os.environ.get("AAU_FUSE_BNRED", "0") != "1"

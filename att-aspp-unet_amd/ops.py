@@ -126,10 +126,21 @@ def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, C
                                  drop_seed, _stream()), "aau_bn_bwd_apply")
 
 
-def bn_bwd_apply_conv1(z, zp, gamma, smean, sinvstd, red, dgamma, dbeta, N, H, W, Cc, dy, dyp, scale, shift, x, dw, ws):
+def bn_bwd_apply_conv1(z, zp, gamma, smean, sinvstd, red, dgamma, dbeta, N, H, W, Cc, dy, dyp, scale, shift, x, dw, ws,
+                       w=None):
+    """z None: recomputed from x and the conv weights ``w`` [C][9]."""
     check(fn("aau_bn_bwd_apply_conv1")(_p(z), zp, _p(gamma), _p(smean), _p(sinvstd), _p(red), _p(dgamma), _p(dbeta),
-                                       N, H, W, Cc, _p(dy), dyp, _p(scale), _p(shift), _p(x), _p(dw), _p(ws), _stream()),
-          "aau_bn_bwd_apply_conv1")
+                                       N, H, W, Cc, _p(dy), dyp, _p(scale), _p(shift), _p(x), _p(w), _p(dw), _p(ws),
+                                       _stream()), "aau_bn_bwd_apply_conv1")
+
+
+def conv1_bn_act(x, w, y, yp, scale, shift, N, H, W, Cc):
+    check(fn("aau_conv1_bn_act")(_p(x), _p(w), _p(y), yp, _p(scale), _p(shift), N, H, W, Cc, _stream()), "aau_conv1_bn_act")
+
+
+def conv1_bn_bwd_reduce(x, w, dy, dyp, scale, shift, smean, sinvstd, red, N, H, W, Cc):
+    check(fn("aau_conv1_bn_bwd_reduce")(_p(x), _p(w), _p(dy), dyp, _p(scale), _p(shift), _p(smean), _p(sinvstd), _p(red),
+                                        N, H, W, Cc, _stream()), "aau_conv1_bn_bwd_reduce")
 
 
 def gap_fwd(x, xp, pooled, ws, N, HW, Cc):

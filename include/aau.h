@@ -192,11 +192,22 @@ int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
 /* First layer (pipeline:113 d1[0]): the apply pass fused with the weight gradient of its   */
 /* Conv2d(1, C, 3, pad 1) -- the layer has no input gradient, so dz is never written.     */
 /* x: the fp32 frame [N][H][W]; dw: [C][9] fp32 (+=); ws: fp32 [32][C*9] scratch.          */
+/* z == NULL: z is recomputed from x and the conv weights w [C][9] (see aau_conv1_bn_act). */
 int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const float* gamma, const float* save_mean,
                            const float* save_invstd, const float* red, float* dgamma, float* dbeta,
                            int N, int H, int W, int C, const aau_bf16* dy, int dy_pitch,
-                           const float* scale, const float* shift, const float* x, float* dw,
-                           float* ws, void* stream);
+                           const float* scale, const float* shift, const float* x, const float* w,
+                           float* dw, float* ws, void* stream);
+/* The first layer's raw output z costs 9 FMAs per value to recompute and 2 bytes to move,   */
+/* so it is never stored in training: aau_conv1_fwd(z = NULL) accumulates the statistics     */
+/* only, and these two recompute z (same fma chain, same bf16 rounding) from the frame:      */
+/* y = relu(bf16(conv1(x))*scale+shift), and the BatchNorm-backward reduce of that layer.     */
+int aau_conv1_bn_act(const float* x, const float* w, aau_bf16* y, int y_pitch, const float* scale,
+                     const float* shift, int N, int H, int W, int C, void* stream);
+int aau_conv1_bn_bwd_reduce(const float* x, const float* w, const aau_bf16* dy, int dy_pitch,
+                            const float* scale, const float* shift, const float* save_mean,
+                            const float* save_invstd, float* red, int N, int H, int W, int C,
+                            void* stream);
 
 /* ---- ASPP image-pool branch (pipeline:75-77,82) -------------------------------------- */
 /* ws: caller-provided fp32 [N*C] workspace (zeroed by the call)                        */

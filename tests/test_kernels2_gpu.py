@@ -470,3 +470,44 @@ def test_network_head_fused_forward_and_backward(ops, C):
     assert rel_err(red1.sum(0).cpu(), red0.sum(0).cpu()) < 1e-5
     assert rel_err(dg1.cpu(), dg0.cpu()) < 1e-5 and rel_err(dbt1.cpu(), dbt0.cpu()) < 1e-5
     assert rel_err(dz1.cpu(), dz0.cpu()) < 1e-2 and float((dz1.float() != dz0.float()).float().mean()) < 1e-2
+
+
+@pytest.mark.parametrize("C", [48, 8, 104])
+def test_first_layer_z_recomputed_instead_of_stored(ops, C):
+    """aau_conv1_bn_act / aau_conv1_bn_bwd_reduce / aau_bn_bwd_apply_conv1(z=NULL) recompute the first layer's z from
+    the frame with the fma chain of aau_conv1_fwd: same bits as the stored-z path."""
+    N, H, W = 2, 24, 40
+    M = N * H * W
+    g = torch.Generator().manual_seed(300 + C)
+    x = dev(torch.randn(N, H, W, generator=g))
+    w = dev(torch.randn(C, 9, generator=g) * 0.4)
+    gy = dev(bf(torch.randn(N, H, W, C, generator=g)))
+    gamma = dev(torch.rand(C, generator=g) + 0.5)
+    # stored-z path
+    z = zeros(N, H, W, C, dtype=torch.bfloat16)
+    st0 = zeros(ops.STAT_REPLICAS, 2, C)
+    ops.conv1_fwd(x, w, z, st0, N, H, W, C)
+    st1 = zeros(ops.STAT_REPLICAS, 2, C)
+    ops.conv1_fwd(x, w, None, st1, N, H, W, C)                       # statistics only
+    zf = z.float().reshape(-1, C)
+    mean, var = zf.mean(0), zf.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma * invstd, torch.randn(C, generator=g).cuda() * 0.2 - mean * gamma * invstd
+    y0, y1 = zeros(N, H, W, C, dtype=torch.bfloat16), zeros(N, H, W, C, dtype=torch.bfloat16)
+    ops.bn_act(z, C, y0, C, scale, shift, M, C, relu=1)
+    ops.conv1_bn_act(x, w, y1, C, scale, shift, N, H, W, C)
+    red0, red1 = zeros(ops.STAT_REPLICAS, 2, C), zeros(ops.STAT_REPLICAS, 2, C)
+    ops.bn_bwd_reduce(z, C, gy, C, None, 0, None, C, scale, shift, mean, invstd, red0, N, H, W, C, relu=1)
+    ops.conv1_bn_bwd_reduce(x, w, gy, C, scale, shift, mean, invstd, red1, N, H, W, C)
+    outs = []
+    for zz, ww in ((z, None), (None, w)):
+        dg, db, dw = zeros(C), zeros(C), zeros(C, 9)
+        ws = torch.full((ops.STAT_REPLICAS * C * 9,), float("nan"), device="cuda")
+        ops.bn_bwd_apply_conv1(zz, C, gamma, mean, invstd, red0, dg, db, N, H, W, C, gy, C, scale, shift, x, dw, ws, w=ww)
+        outs.append((dg, db, dw))
+    torch.cuda.synchronize()
+    assert rel_err(st1.sum(0).cpu(), st0.sum(0).cpu()) < 1e-5
+    assert torch.equal(y1, y0)
+    assert rel_err(red1.sum(0).cpu(), red0.sum(0).cpu()) < 1e-5
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel_err(outs[1][2].cpu(), outs[0][2].cpu()) < 1e-5
