@@ -46,17 +46,22 @@ struct W3Args {
 // QT = 16-channel q tiles per workgroup (3: 48 channels, 6: 96 channels); PR = patch rows per K-step.
 // <3, 8> (default): 21 accumulator tiles per wave, 20 transposed reads per 21 MFMAs, 2 waves per SIMD;
 // <6, 4> (opt-in): 42 tiles per wave, half the LDS reads per FLOP, but 200 VGPRs -> 1 wave per SIMD.
-template <int QT, int PR>
-__global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
+// NG = 2 (with QT = 6): 8 waves, two groups of four that share the staged x halo; group g owns q tiles 3g..3g+2 of the
+// 96-channel dz tile.  Same accumulators per wave and waves per SIMD as <3, 8, 1> at two workgroups per CU, but the
+// halo is staged once per 96 output channels instead of once per 48: -29 % L2 -> LDS fill bytes per FLOP.
+template <int QT, int PR, int NG = 1>
+__global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
     constexpr int BQ = QT * 16;
+    constexpr int NW = 4 * NG;                            // waves
+    constexpr int QW = QT / NG;                           // q tiles per wave
     constexpr int NPX = PR * 16;                          // pixels per K-step
     constexpr int QS = BQ / 8;                            // 16-B slots per dz row
     constexpr int YPITCH = BQ * 2;                        // 96 or 192 bytes
-    constexpr int NLY = (NPX * QS + 255) / 256;           // LDS-DMA instructions per wave per K-step (dz tile)
-    constexpr int YB = NLY * 4 * 1024;                    // staged bytes (pieces past the tile are zero fill)
+    constexpr int NLY = (NPX * QS + 64 * NW - 1) / (64 * NW);   // LDS-DMA instructions per wave per K-step (dz tile)
+    constexpr int YB = NLY * NW * 1024;                    // staged bytes (pieces past the tile are zero fill)
     constexpr int XROWS = (PR + 2) * 18;                  // halo pixels
-    constexpr int NLX = (XROWS * 6 + 255) / 256;          // LDS-DMA instructions per wave per K-step (x halo)
-    constexpr int XB = NLX * 4 * 1024;                    // staged bytes (rows >= XROWS are zero fill)
+    constexpr int NLX = (XROWS * 6 + 64 * NW - 1) / (64 * NW);  // LDS-DMA instructions per wave per K-step (x halo)
+    constexpr int XB = NLX * NW * 1024;                    // staged bytes (rows >= XROWS are zero fill)
     constexpr unsigned OOB = 0x80000000u;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    const int wc = wave & 3, grp = wave >> 2;   // column-tile wave, q group
 
     const int ntc = (d.Cin + 47) / 48;
     int bid = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
@@ -80,7 +86,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     const int p_end = min(a.npatch, p_begin + a.patches_per_block);
     if (p_begin >= p_end) {   // never taken with the host's split sizes, but a slab must not stay unwritten
         if (a.ws)
-            for (int v = 0; v < QT * 7; ++v) *(f32x4*)(a.ws + ((int64_t)lbid * QT * 7 * 256 + v * 256 + threadIdx.x) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int v = grp * QW * 7; v < (grp + 1) * QW * 7; ++v)
+                *(f32x4*)(a.ws + ((int64_t)lbid * QT * 7 * 256 + v * 256 + (threadIdx.x & 255)) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
 
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     int yrel[NLY];     // element offset of (patch row, column, channel slot) relative to the patch origin, or -1
 #pragma unroll
     for (int i = 0; i < NLY; ++i) {
-        const int p = (i * 4 + wave) * 64 + lane;
+        const int p = (i * NW + wave) * 64 + lane;
         const int px = p / QS, s = p - px * QS;
         const int r = px >> 4, cx = px & 15;
         // 192-byte rows: XOR the 32-B granule with bit 2 of the row (source side), see wgrad.hip
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
     int xhy[NLX], xhx[NLX], xch[NLX];
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
-        const int p = (i * 4 + wave) * 64 + lane;
+        const int p = (i * NW + wave) * 64 + lane;
         const int px = p / 6, s = p - px * 6;
         const int hy = px / 18, hx = px - hy * 18;
         xhy[i] = (px < XROWS && c0 + s * 8 < d.Cin) ? hy : -100000;
@@ -119,28 +126,28 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
 #pragma unroll
         for (int i = 0; i < NLY; ++i) {
             const unsigned v = yrel[i] >= 0 ? (unsigned)((org * d.dst_pitch + yrel[i]) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY(buf) + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY(buf) + (i * NW + wave) * 1024), 16, (int)v, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
             const int y = y0 - 1 + xhy[i], x = x0 - 1 + xhx[i];
             const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
             const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + xch[i]) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX(buf) + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX(buf) + (i * NW + wave) * 1024), 16, (int)v, 0, 0, 0);
         }
     };
 
     // ---- this wave's column tiles: ct = 7*wave + n, n = 0..6 (tap = ct/3, channel group j = ct%3) ----
-    f32x4 acc[QT][7];
+    f32x4 acc[QW][7];
 #pragma unroll
-    for (int i = 0; i < QT; ++i)
+    for (int i = 0; i < QW; ++i)
 #pragma unroll
         for (int n = 0; n < 7; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     int coff[7];    // byte offset inside the halo image of (tap shift, channel group) for column tile n
-    const int nct = (wave == 3) ? 6 : 7;
+    const int nct = (wc == 3) ? 6 : 7;
 #pragma unroll
     for (int n = 0; n < 7; ++n) {
-        int ct = 7 * wave + n;
+        int ct = 7 * wc + n;
         if (ct > 26) ct = 26;
         const int tap = ct / 3, j = ct - tap * 3;
         const int ty = tap / 3, tx = tap - ty * 3;
@@ -156,17 +163,18 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
         const unsigned char* bx = sX(buf);
 #pragma unroll
         for (int ss = 0; ss < PR / 2; ++ss) {
-            bf16x8 af[QT];
+            bf16x8 af[QW];
 #pragma unroll
-            for (int i = 0; i < QT; ++i) {
+            for (int i = 0; i < QW; ++i) {
                 const int r0 = (2 * ss) * 16 + yrow, r1 = r0 + 16;
+                const int gi = grp * QW + i;          // q tile inside the staged dz tile
                 int o0, o1;
                 if constexpr (QT == 3) {
-                    o0 = r0 * 96 + i * 32 + cp * 2;
-                    o1 = r1 * 96 + i * 32 + cp * 2;
+                    o0 = r0 * 96 + gi * 32 + cp * 2;
+                    o1 = r1 * 96 + gi * 32 + cp * 2;
                 } else {   // granule swizzle of the 192-byte rows
-                    o0 = r0 * 192 + ((i ^ ((r0 >> 2) & 1)) * 32) + cp * 2;
-                    o1 = r1 * 192 + ((i ^ ((r1 >> 2) & 1)) * 32) + cp * 2;
+                    o0 = r0 * 192 + ((gi ^ ((r0 >> 2) & 1)) * 32) + cp * 2;
+                    o1 = r1 * 192 + ((gi ^ ((r1 >> 2) & 1)) * 32) + cp * 2;
                 }
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o0));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o1));
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bx + o + 18 * 96));
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                    for (int i = 0; i < QT; ++i)
+                    for (int i = 0; i < QW; ++i)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
 
                 }
@@ -211,21 +219,21 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(const W3Args a) {
         for (int n = 0; n < 7; ++n) {
             if (n >= nct) continue;
 #pragma unroll
-            for (int i = 0; i < QT; ++i) *(f32x4*)(slab + ((i * 7 + n) * 256 + tid) * 4) = acc[i][n];
+            for (int i = 0; i < QW; ++i) *(f32x4*)(slab + (((grp * QW + i) * 7 + n) * 256 + (tid & 255)) * 4) = acc[i][n];
         }
         return;
     }
 #pragma unroll
     for (int n = 0; n < 7; ++n) {
         if (n >= nct) continue;
-        const int ct = 7 * wave + n;
+        const int ct = 7 * wc + n;
         const int tap = ct / 3, j = ct - tap * 3;
         const int c = c0 + j * 16 + li;
 #pragma unroll
-        for (int i = 0; i < QT; ++i)
+        for (int i = 0; i < QW; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int q = q0 + i * 16 + 4 * g16 + r;
+                const int q = q0 + (grp * QW + i) * 16 + 4 * g16 + r;
                 if (q < d.Cout && c < d.Cin) WG_ADD(a.dw + ((int64_t)q * 9 + tap) * d.Cin + c, acc[i][n][r]);
             }
     }
@@ -236,7 +244,7 @@ bool wgrad3x3_applicable(const aau_conv_desc* d) {
            d->W == d->Wo && d->H % 8 == 0 && d->W % 16 == 0;
 }
 
-template <int QT, int PR>
+template <int QT, int PR, int NG = 1>
 static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
     constexpr int BQ = QT * 16;
     a.tiles_x = d->W / 16;
@@ -247,8 +255,8 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_by
     // are NOT hidden behind other workgroups once the whole grid is resident: a plain-store ablation of this
     // epilogue (-DABL_NOATOMIC) is 20-35 us faster per launch.  One resident round (2 workgroups per CU) is the
     // measured optimum for every layer; 1024 cost +15-30 % on the 174-GFLOP layers, 256 +30 % on the others.
-    int64_t target = 512;
-    if (const char* e = getenv("AAU_W3_TARGET")) target = atoi(e);   // experiment
+    int64_t target = 512 / NG;                                       // NG = 2: one 8-wave workgroup per CU
+    if (const char* e = getenv("AAU_W3_TARGET")) target = atoi(e) / NG;   // experiment
     int64_t nsplit = (target + tiles / 2) / tiles;
     const int64_t maxsplit = (a.npatch + 3) / 4;             // at least 4 K-steps per workgroup
     if (nsplit > maxsplit) nsplit = maxsplit;
@@ -265,7 +273,7 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_by
     }
     a.ws = ws;
     a.rev = next_traversal();
-    hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR, NG>), dim3((unsigned)grid), dim3(256 * NG), 0, s, a);
     if (!ws) return check_launch("aau_conv_wgrad(3x3)");
     WRedArgs r;
     r.ws = ws; r.dw = a.dw;
@@ -289,6 +297,7 @@ int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16*
     // 1.7-1.9x SLOWER than <3, 8> at 2 waves per SIMD on the same device, so it stays opt-in (experiments).
     if (d->Cout > 48 && getenv("AAU_W3_WIDE")) return launch_w3<6, 4>(a, d, ws, ws_bytes, need, s);
     if (getenv("AAU_W3_PR4")) return launch_w3<3, 4>(a, d, ws, ws_bytes, need, s);   // experiment: 4 workgroups per CU
+    if (d->Cout > 48 && getenv("AAU_W3_NG2")) return launch_w3<6, 8, 2>(a, d, ws, ws_bytes, need, s);   // experiment
     return launch_w3<3, 8>(a, d, ws, ws_bytes, need, s);
 }
 
