@@ -243,3 +243,46 @@ def test_other_shapes_and_rates_against_emulated_oracle(A, cfg):
     ref.eval(); m.eval()
     with torch.no_grad():
         assert rel(m(x.cuda()), ref(x)) < 3e-2
+
+
+def test_benchmark_configuration_step_matches_oracle(A):
+    """The configuration bench.py measures (base_c 48, 1x512x512; batch 4 here to keep the CPU oracle at a few seconds):
+    this is where the resident-weight / two-stream 3x3 kernels, the slab split-K weight gradients, the fused network
+    head and the fused first-layer backward are actually selected.  One full training step against the CPU oracle
+    with bf16 storage emulation (random init, so gradients are compared by global statistics, see module docstring)."""
+    from att_aspp_unet_amd import synth
+    torch.manual_seed(5)
+    ref = O.AttentionASPPUNet(base_c=48)
+    m = A.AttentionASPPUNet(base_c=48)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda().train()
+    ref.train()
+    ref.bridge.project[3].p = 0.0
+    m.bridge.project[3].p = 0.0
+    x, y = synth.make_frames(4, 512, seed=21)
+    O.emulate_bf16_storage(ref)
+    args = main_args()
+    lo = ref(x)
+    loss_o = O.build_criterion(args, O.ComboLoss(), O.EdgeLoss())(lo, y)
+    loss_o.backward()
+    step = A.TrainStep(m, A.FusedAdamW(m, lr=0.0), args, None)      # lr 0: gradients stay inspectable, weights fixed
+    loss_e = float(step(x.cuda(), y.cuda()).item())
+    plan = m._plan_for(x.cuda())
+    le = plan.logits.clone()
+    named = list(m.named_parameters())
+    ge = torch.cat([p.grad.detach().double().cpu().flatten() for _, p in named])
+    gr = torch.cat([p.grad.detach().double().flatten() for _, p in ref.named_parameters()])
+    cos = float(torch.dot(ge, gr) / ge.norm() / gr.norm())
+    stats = dict(logit_max=rel(le, lo), logit_mean=float((le.cpu() - lo.detach()).abs().mean() / lo.detach().abs().max()),
+                 loss=(loss_e, float(loss_o)), cos=cos, gnorm=(float(ge.norm()), float(gr.norm())))
+    print(stats)
+    # 1M logits: the maximum is a tail statistic of the bf16 path (3 % at the 65k-pixel fixtures)
+    assert stats["logit_max"] < 6e-2 and stats["logit_mean"] < 4e-3, stats
+    assert abs(loss_e - float(loss_o)) < 2e-3 * float(loss_o), stats
+    assert cos > 0.97, stats
+    assert abs(float(ge.norm()) - float(gr.norm())) < 0.05 * float(gr.norm()), stats
+    # running statistics of the first and the last BatchNorm
+    sd_e, sd_o = m.state_dict(), ref.state_dict()
+    for k in ("d1.0.block.1.running_mean", "d1.0.block.1.running_var", "u1.conv.1.block.1.running_mean",
+              "u1.conv.1.block.1.running_var"):
+        assert rel(sd_e[k], sd_o[k]) < 4e-2, k
