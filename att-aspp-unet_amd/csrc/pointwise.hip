@@ -292,6 +292,41 @@ __global__ __launch_bounds__(256) void bn_act_outconv_kernel(const unsigned shor
     }
 }
 
+// Same, for C <= 512: a pixel's channels are spread over CG = C/8 consecutive lanes of ONE wave (16-B loads, contiguous
+// across lanes) and the per-pixel dot product is finished with CG-1 wave shuffles.  The one-thread-per-pixel form
+// above reads 96-byte-strided pieces and ran at 1.7 TB/s.  The summation order differs from outconv_fwd's, so the
+// logits agree to fp32 rounding, not bitwise.
+__global__ __launch_bounds__(256) void bn_act_outconv_wave_kernel(const unsigned short* z, int zp, const float* scale,
+                                                                  const float* shift, const float* w, const float* b,
+                                                                  float* logits, int64_t M, int C, int rev) {
+    const int CG = C >> 3;
+    const int ppw = 64 / CG;                       // pixels per wave pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane % CG, pw = lane / CG;      // lanes >= ppw*CG idle
+    const bool act = pw < ppw;
+    const int c = cg * 8;
+    float sc[8], sh[8], wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[c + j]; sh[j] = shift[c + j]; wv[j] = w[c + j]; }
+    const float bias = b ? b[0] : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 4 * ppw;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * ppw; base < M; base += stride) {
+        const int64_t i = base + pw;
+        const bool ok = act && i < M;
+        const int64_t m = rev ? M - 1 - i : i;
+        float acc = 0.f;
+        if (ok) {
+            float f[8];
+            unpack8(*(const u32x4*)(z + m * zp + c), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += bf2f(f2bf(fmaxf(f[j] * sc[j] + sh[j], 0.f))) * wv[j];
+        }
+        float tot = acc;
+        for (int o = 1; o < CG; ++o) tot += __shfl_down(acc, o, 64);   // lanes cg == 0 end with the pixel's sum
+        if (ok && cg == 0) logits[m] = tot + bias;
+    }
+}
+
 // ---- network head, backward: the gradient w.r.t. the last activation is rank one (dlogits[m] * w[c]), so it is
 // never materialised either.  This pass = outconv_bwd (dw += sum dl*y, db += sum dl, y recomputed from z) +
 // bn_bwd_reduce of the last BatchNorm (g = [y>0] * bf16(dl*w), sums of g and g*zhat).  ws: [R][C+8] replicas of
@@ -698,8 +733,15 @@ extern "C" int aau_bn_act_outconv(const aau_bf16* z, int z_pitch, const float* s
     CHK_C("aau_bn_act_outconv", C);
     AAU_REQUIRE(z_pitch % 8 == 0, "aau_bn_act_outconv: pitch");
     ProfScope prof(2, 4.0 * M * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_act_outconv_kernel, dim3(grid1d(M)), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream, z,
-                       z_pitch, scale, shift, w, b, logits, M, C, next_traversal());
+    const int rev = next_traversal();
+    if (C <= 512) {
+        const int ppw = 64 / (C >> 3);
+        hipLaunchKernelGGL(bn_act_outconv_wave_kernel, dim3(grid1d((M + ppw - 1) / ppw * 64, 8192)), dim3(256), 0,
+                           (hipStream_t)stream, z, z_pitch, scale, shift, w, b, logits, M, C, rev);
+    } else {
+        hipLaunchKernelGGL(bn_act_outconv_kernel, dim3(grid1d(M)), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream, z,
+                           z_pitch, scale, shift, w, b, logits, M, C, rev);
+    }
     return check_launch("aau_bn_act_outconv");
 }
 

@@ -263,7 +263,7 @@ int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlogits, const 
                     void* stream);
 /* Network head in training (pipeline:121-122,126: the last ConvBNReLU feeds out_conv only).    */
 /* forward: logits[m] = b + sum_c w[c] * bf16(relu(z[m][c]*scale[c]+shift[c])) -- the activated   */
-/* tensor is never written (bitwise the logits of aau_bn_act + aau_outconv_fwd).                 */
+/* tensor is never written (the logits of aau_bn_act + aau_outconv_fwd up to fp32 summation order). */
 int aau_bn_act_outconv(const aau_bf16* z, int z_pitch, const float* scale, const float* shift,
                        const float* w, const float* b, float* logits, int64_t M, int C, void* stream);
 /* backward: the gradient w.r.t. that activation is rank one, dy[m][c] = bf16(dlogits[m]*w[c]),   */

@@ -465,7 +465,7 @@ def test_network_head_fused_forward_and_backward(ops, C):
     dz1, dg1, dbt1 = zeros(M, C, dtype=torch.bfloat16), zeros(C), zeros(C)
     ops.bn_bwd_apply_rank1(z, C, dz1, C, dev(gamma), dev(mean), dev(invstd), red1, dg1, dbt1, M, C, dl, w, scale, shift)
     torch.cuda.synchronize()
-    assert torch.equal(lg1, lg0)
+    assert rel_err(lg1.cpu(), lg0.cpu()) < 1e-5               # same products, different summation order
     assert rel_err(dw1.cpu(), dw0.cpu()) < 1e-5 and rel_err(db1.cpu(), db0.cpu()) < 1e-5
     assert rel_err(red1.sum(0).cpu(), red0.sum(0).cpu()) < 1e-5
     assert rel_err(dg1.cpu(), dg0.cpu()) < 1e-5 and rel_err(dbt1.cpu(), dbt0.cpu()) < 1e-5
