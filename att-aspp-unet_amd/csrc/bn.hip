@@ -117,10 +117,8 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const unsigned short* y, 
     for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
         const int64_t mo = v / CG;
         const int c = (int)(v - mo * CG) * 8;
-        const int xo = (int)(mo % Wo);
-        const int64_t t = mo / Wo;
-        const int yo = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        int xo, yo, n;
+        decode3(mo, Wo, Ho, xo, yo, n);
         const unsigned short* b = y + (((int64_t)n * H + 2 * yo) * W + 2 * xo) * yp + c;
         float a0[8], a1[8], a2[8], a3[8];
         unpack8(ld16(b), a0);
@@ -149,10 +147,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const unsigned short* 
     ldf8(shift + c, sh);
     const int64_t i0 = slice_begin(ipb), i1 = min(total, i0 + ipb);
     for (int64_t mo = i0 + pl; mo < i1; mo += mp.PL) {
-        const int xo = (int)(mo % Wo);
-        const int64_t t = mo / Wo;
-        const int yo = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        int xo, yo, n;
+        decode3(mo, Wo, Ho, xo, yo, n);
         const int64_t p00 = ((int64_t)n * H + 2 * yo) * W + 2 * xo;
         const int64_t pix[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
         float best[8];
@@ -197,10 +193,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const int64_t i1 = min(nitems, i0 + items_per_block);
         for (int64_t it = i0 + pl; it < i1; it += mp.PL) {
             if constexpr (POOL) {
-                const int xo = (int)(it % Wo);
-                const int64_t t = it / Wo;
-                const int yo = (int)(t % Ho);
-                const int n = (int)(t / Ho);
+                int xo, yo, n;
+                decode3(it, Wo, Ho, xo, yo, n);
                 const int64_t p00 = ((int64_t)n * H + 2 * yo) * W + 2 * xo;
                 const int64_t pix[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
                 float zz[4][8], yy[4][8], g[4][8], dp[8];
@@ -547,6 +541,7 @@ extern "C" int aau_bn_act_pool(const aau_bf16* z, int z_pitch, aau_bf16* y, int 
     AAU_REQUIRE(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "aau_bn_act_pool: H=%d W=%d must be even", H, W);
     CHK_C("aau_bn_act_pool", C);
     AAU_REQUIRE(z_pitch % 8 == 0 && y_pitch % 8 == 0 && p_pitch % 8 == 0, "aau_bn_act_pool: pitches must be multiples of 8");
+    AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_bn_act_pool: pixel count overflows int32");
     ProfScope prof(2, 0, (hipStream_t)stream);
     int64_t blocks, ipb;
     rows_split((int64_t)N * (H / 2) * (W / 2), CGMap(C).PL, &blocks, &ipb);
@@ -562,6 +557,7 @@ extern "C" int aau_maxpool2(const aau_bf16* y, int y_pitch, aau_bf16* p, int p_p
     AAU_REQUIRE(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "aau_maxpool2: H=%d W=%d must be even", H, W);
     CHK_C("aau_maxpool2", C);
     AAU_REQUIRE(y_pitch % 8 == 0 && p_pitch % 8 == 0, "aau_maxpool2: pitches must be multiples of 8");
+    AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_maxpool2: pixel count overflows int32");
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
                        (hipStream_t)stream, y, y_pitch, p, p_pitch, N, H, W, C);
@@ -584,6 +580,7 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
     if (dpool) {
         AAU_REQUIRE(H % 2 == 0 && W % 2 == 0, "aau_bn_bwd_reduce: pooled source needs even H, W");
         AAU_REQUIRE(drop_p == 0.f, "aau_bn_bwd_reduce: dropout and pooling do not combine");
+        AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_bn_bwd_reduce: pixel count overflows int32");
         const int64_t items = (int64_t)N * (H / 2) * (W / 2);
         int64_t blocks = (items + mp.PL * 4 - 1) / (mp.PL * 4);
         if (blocks > 2048) blocks = 2048;

@@ -83,6 +83,17 @@ __device__ __forceinline__ void conv1_taps(const float* img, int yy, int xx, int
         }
 }
 
+// Flat index -> coordinates with 32-bit unsigned division (indices stay below 2^31; the int64 form of % and / costs
+// on the order of a hundred VALU instructions per pixel and showed up as 30-40 % of the pooled BN kernels).
+__device__ __forceinline__ void decode3(int64_t i, int W, int H, int& x, int& y, int& n) {
+    const unsigned u = (unsigned)i;
+    const unsigned t = u / (unsigned)W;
+    x = (int)(u - t * (unsigned)W);
+    const unsigned nn = t / (unsigned)H;
+    y = (int)(t - nn * (unsigned)H);
+    n = (int)nn;
+}
+
 // First row of this workgroup's slice of a row-split launch.  A NEGATIVE rows-per-block encodes "walk the tensor
 // from its end" (aau_traverse): workgroup b then owns slice gridDim.x-1-b.  Makes rpb positive.
 template <typename T>

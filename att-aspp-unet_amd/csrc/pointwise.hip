@@ -52,9 +52,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* x, const fl
         const int64_t M = (int64_t)N * H * W;
         const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
-            const int xx = (int)(m % W);
-            const int64_t t = m / W;
-            const int yy = (int)(t % H);
+            int xx, yy, nimg;
+            decode3(m, W, H, xx, yy, nimg);
+            const int64_t t = (int64_t)nimg * H + yy;
             const float* img = x + (t - yy) * W;  // start of image n
             float v[9];
             conv1_taps(img, yy, xx, H, W, v);
@@ -101,9 +101,9 @@ __global__ __launch_bounds__(256) void conv1_bn_act_kernel(const float* x, const
     const int64_t M = (int64_t)N * H * W;
     const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
     for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
-        const int xx = (int)(m % W);
-        const int64_t t = m / W;
-        const int yy = (int)(t % H);
+        int xx, yy, nimg;
+        decode3(m, W, H, xx, yy, nimg);
+        const int64_t t = (int64_t)nimg * H + yy;
         float v[9], o[8];
         conv1_taps(x + (t - yy) * W, yy, xx, H, W, v);
 #pragma unroll
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_reduce_kernel(const float* x
         const int64_t M = (int64_t)N * H * W;
         const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
-            const int xx = (int)(m % W);
-            const int64_t t = m / W;
-            const int yy = (int)(t % H);
+            int xx, yy, nimg;
+            decode3(m, W, H, xx, yy, nimg);
+            const int64_t t = (int64_t)nimg * H + yy;
             float v[9], g[8];
             unpack8(*(const u32x4*)(dy + m * dyp + c), g);
             conv1_taps(x + (t - yy) * W, yy, xx, H, W, v);
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* x, const 
         const int64_t M = (int64_t)N * H * W;
         const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
         for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
-            const int xx = (int)(m % W);
-            const int64_t t = m / W;
-            const int yy = (int)(t % H);
+            int xx, yy, nimg;
+            decode3(m, W, H, xx, yy, nimg);
+            const int64_t t = (int64_t)nimg * H + yy;
             const float* img = x + (t - yy) * W;
             float g[8];
             unpack8(*(const u32x4*)(dz + m * C + c), g);
@@ -563,6 +563,7 @@ using namespace aau;
 extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, float* stats, int N, int H, int W, int C,
                              void* stream) {
     AAU_REQUIRE(x && w && (z || stats) && N > 0 && H > 0 && W > 0, "aau_conv1_fwd: bad args");
+    AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_conv1_fwd: pixel count overflows int32");
     CHK_C("aau_conv1_fwd", C);
     const CGMap2 mp(C);
     int64_t blocks, ppb;
@@ -577,6 +578,7 @@ extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, float*
 extern "C" int aau_conv1_wgrad(const float* x, const aau_bf16* dz, float* dw, int N, int H, int W, int C,
                                void* stream) {
     AAU_REQUIRE(x && dz && dw && N > 0 && H > 0 && W > 0, "aau_conv1_wgrad: bad args");
+    AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_conv1_wgrad: pixel count overflows int32");
     CHK_C("aau_conv1_wgrad", C);
     const CGMap2 mp(C);
     int64_t blocks, ppb;
@@ -771,7 +773,7 @@ extern "C" int aau_conv1_bn_act(const float* x, const float* w, aau_bf16* y, int
     AAU_REQUIRE(x && w && y && scale && shift && N > 0 && H > 0 && W > 0, "aau_conv1_bn_act: bad args");
     CHK_C("aau_conv1_bn_act", C);
     AAU_REQUIRE(y_pitch % 8 == 0, "aau_conv1_bn_act: pitch");
-    AAU_REQUIRE((int64_t)H * W < 0x7fffffff, "aau_conv1_bn_act: image too large");
+    AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_conv1_bn_act: pixel count overflows int32");
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows((int64_t)N * H * W, mp.PL, 16, 4096, &blocks, &ppb);
@@ -789,7 +791,7 @@ extern "C" int aau_conv1_bn_bwd_reduce(const float* x, const float* w, const aau
                 "aau_conv1_bn_bwd_reduce: bad args");
     CHK_C("aau_conv1_bn_bwd_reduce", C);
     AAU_REQUIRE(dy_pitch % 8 == 0, "aau_conv1_bn_bwd_reduce: pitch");
-    AAU_REQUIRE((int64_t)H * W < 0x7fffffff, "aau_conv1_bn_bwd_reduce: image too large");
+    AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_conv1_bn_bwd_reduce: pixel count overflows int32");
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows((int64_t)N * H * W, mp.PL, 32, 2048, &blocks, &ppb);
