@@ -59,11 +59,11 @@ _SIGS = {
     "aau_pack_weights": [P, P, P, I, L, P],
     "aau_bn_finalize": [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
     "aau_bn_fold_eval": [P, P, P, P, P, P, I, F, P],
-    "aau_bn_act": [P, I, P, I, P, P, L, I, I, L, F, U64, P],
+    "aau_bn_act": [P, I, P, I, P, P, L, I, I, L, F, P, P],
     "aau_bn_act_pool": [P, I, P, I, P, I, P, P, I, I, I, I, P],
     "aau_maxpool2": [P, I, P, I, I, I, I, I, P],
-    "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, U64, P],
-    "aau_bn_bwd_apply": [P, I, P, I, P, P, P, P, P, P, L, I, P, I, P, P, I, F, U64, P],
+    "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, P, P],
+    "aau_bn_bwd_apply": [P, I, P, I, P, P, P, P, P, P, L, I, P, I, P, P, I, F, P, P],
     "aau_bn_bwd_apply_conv1": [P, I, P, P, P, P, P, P, I, I, I, I, P, I, P, P, P, P, P, P, P],
     "aau_conv1_bn_act": [P, P, P, I, P, P, I, I, I, I, P],
     "aau_conv1_bn_bwd_reduce": [P, P, P, I, P, P, P, P, P, I, I, I, I, P],

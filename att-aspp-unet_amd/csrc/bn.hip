@@ -84,7 +84,7 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
 // registers) and walks over pixels; consecutive threads cover consecutive 16-B vectors of a pixel row.
 __global__ __launch_bounds__(256) void bn_act_kernel(const unsigned short* z, int zp, unsigned short* y, int yp,
                                                      const float* scale, const float* shift, int64_t M, int C,
-                                                     int relu, int64_t bhw, float drop_p, uint64_t seed,
+                                                     int relu, int64_t bhw, float drop_p, const uint64_t* seedp,
                                                      int64_t ppb) {
     const CGMap mp(C);
     const int tid = threadIdx.x;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const unsigned short* z, in
     ldf8(scale + c, sc);
     ldf8(shift + c, sh);
     const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const uint64_t seed = drop_p > 0.f ? *seedp : 0;   // device-resident: a captured hipGraph sees a fresh value per replay
     const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
     for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
         const int64_t ms = bhw > 0 ? m / bhw : m;
@@ -174,7 +175,8 @@ template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const unsigned short* z, int zp, const unsigned short* dy, int dyp, const unsigned short* dpool, int dpp,
     unsigned short* dz, int dzp, const float* scale, const float* shift, const float* mean, const float* invstd,
-    float* red, int N, int H, int W, int C, int relu, float drop_p, uint64_t seed, int64_t items_per_block) {
+    float* red, int N, int H, int W, int C, int relu, float drop_p, const uint64_t* seedp, int64_t items_per_block) {
+    const uint64_t seed = drop_p > 0.f ? *seedp : 0;   // device-resident: a captured hipGraph sees a fresh value per replay
     __shared__ float sred[256 * 8];
     const CGMap mp(C);
     const int tid = threadIdx.x;
@@ -274,8 +276,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
                                                            const float* gamma, const float* mean, const float* invstd,
                                                            const float* red, float* dgamma, float* dbeta, int64_t M,
                                                            int C, const unsigned short* dy, int dyp, const float* scale,
-                                                           const float* shift, int relu, float drop_p, uint64_t seed,
+                                                           const float* shift, int relu, float drop_p, const uint64_t* seedp,
                                                            const float* dl, const float* wout, int64_t ppb) {
+    const uint64_t seed = drop_p > 0.f ? *seedp : 0;
     extern __shared__ float sm[];   // [2][C] replica sums, computed once per workgroup
     for (int cc = threadIdx.x; cc < C; cc += 256) {
         float a = 0.f, b = 0.f;
@@ -521,7 +524,7 @@ extern "C" int aau_bn_fold_eval(const float* gamma, const float* beta, const flo
 
 extern "C" int aau_bn_act(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pitch, const float* scale,
                           const float* shift, int64_t M, int C, int relu, int64_t bcast_hw, float drop_p,
-                          uint64_t drop_seed, void* stream) {
+                          const uint64_t* drop_seed, void* stream) {
     AAU_REQUIRE(z && y && scale && shift && M > 0, "aau_bn_act: bad args");
     CHK_C("aau_bn_act", C);
     AAU_REQUIRE(z_pitch % 8 == 0 && y_pitch % 8 == 0, "aau_bn_act: pitches must be multiples of 8");
@@ -568,7 +571,7 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
                                  const aau_bf16* dpool, int dpool_pitch, aau_bf16* dz, int dz_pitch,
                                  const float* scale, const float* shift, const float* save_mean,
                                  const float* save_invstd, float* red, int N, int H, int W, int C, int relu,
-                                 float drop_p, uint64_t drop_seed, void* stream) {
+                                 float drop_p, const uint64_t* drop_seed, void* stream) {
     AAU_REQUIRE(z && scale && shift && save_mean && save_invstd && red, "aau_bn_bwd_reduce: null pointer");
     AAU_REQUIRE(dz || !dpool, "aau_bn_bwd_reduce: the pooled form must store the masked gradient (dz != NULL)");
     AAU_REQUIRE(dy || dpool, "aau_bn_bwd_reduce: needs at least one gradient source");
@@ -607,7 +610,7 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
 extern "C" int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch, const float* gamma,
                                 const float* save_mean, const float* save_invstd, const float* red, float* dgamma,
                                 float* dbeta, int64_t M, int C, const aau_bf16* dy, int dy_pitch, const float* scale,
-                                const float* shift, int relu, float drop_p, uint64_t drop_seed, void* stream) {
+                                const float* shift, int relu, float drop_p, const uint64_t* drop_seed, void* stream) {
     AAU_REQUIRE(z && dz && gamma && save_mean && save_invstd && red && M > 0, "aau_bn_bwd_apply: bad args");
     AAU_REQUIRE(!dy || (scale && shift && dy_pitch % 8 == 0), "aau_bn_bwd_apply: dy needs scale/shift and an aligned pitch");
     CHK_C("aau_bn_bwd_apply", C);
@@ -636,7 +639,7 @@ extern "C" int aau_bn_bwd_apply_rank1(const aau_bf16* z, int z_pitch, aau_bf16* 
     if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, z, z_pitch, dz,
                        dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, M, C, (const unsigned short*)nullptr, 0,
-                       scale, shift, 1, 0.f, (uint64_t)0, dlogits, w_out, ppb);
+                       scale, shift, 1, 0.f, (const uint64_t*)nullptr, dlogits, w_out, ppb);
     return check_launch("aau_bn_bwd_apply_rank1");
 }
 

@@ -291,7 +291,8 @@ class Plan:
         self.eng, self.B, self.H, self.W, self.train = eng, B, H, W, train
         self.dev = eng.store.device
         self.fwd, self.bwd = _Rec(), _Rec()
-        self.drop_seed = C.c_uint64(0)
+        # dropout seed in device memory, advanced on the stream once per training forward (graph-capturable)
+        self.drop_seed = torch.tensor([eng.next_seed() >> 1], dtype=torch.int64, device=eng.store.device)
         self.drop_p = float(eng.model.bridge.project[3].p) if train else 0.0
         st = eng.store
         nbn = st.bn_channels + 8
@@ -669,7 +670,7 @@ class Plan:
             self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
         if self.train:
             self.stats_arena.buf.zero_()
-            self.drop_seed.value = self.eng.next_seed()
+            self.drop_seed.add_(0x9E3779B97F4A7C15 - (1 << 64))   # odd increment mod 2^64: a new mask every step
         self.fwd.run(stream)
         return self.logits
 

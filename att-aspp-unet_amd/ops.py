@@ -23,6 +23,17 @@ def _p(t) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+def _seed_ptr(seed, drop_p):
+    """Dropout seeds live in device memory (a captured step must see a new one per replay).  Accepts a device int64
+    tensor (the engine's) or, for one-off calls, a Python int."""
+    if drop_p <= 0.0 or seed is None:
+        return None, None
+    if isinstance(seed, torch.Tensor):
+        return seed.data_ptr(), seed
+    t = torch.tensor([int(seed) - (1 << 64) if int(seed) >= (1 << 63) else int(seed)], dtype=torch.int64, device="cuda")
+    return t.data_ptr(), t
+
+
 def pitch_of(t: torch.Tensor) -> int:
     """Pixel pitch (elements) of an NHWC tensor/view whose last dim is contiguous."""
     assert t.stride(-1) == 1, "channel dimension must be contiguous"
@@ -99,8 +110,9 @@ def bn_fold_eval(gamma, beta, rmean, rvar, scale, shift, Cc, eps=1e-5):
 
 
 def bn_act(z, zp, y, yp, scale, shift, M, Cc, relu=1, bcast_hw=0, drop_p=0.0, drop_seed=0):
+    sp, _keep = _seed_ptr(drop_seed, drop_p)
     check(fn("aau_bn_act")(_p(z), zp, _p(y), yp, _p(scale), _p(shift), M, Cc, relu, bcast_hw, drop_p,
-                           drop_seed, _stream()), "aau_bn_act")
+                           sp, _stream()), "aau_bn_act")
 
 
 def bn_act_pool(z, zp, y, yp, p, pp, scale, shift, N, H, W, Cc):
@@ -114,16 +126,18 @@ def maxpool2(y, yp, p, pp, N, H, W, Cc):
 
 def bn_bwd_reduce(z, zp, dy, dyp, dpool, dpp, dz, dzp, scale, shift, smean, sinvstd, red, N, H, W, Cc,
                   relu=1, drop_p=0.0, drop_seed=0):
+    sp, _keep = _seed_ptr(drop_seed, drop_p)
     check(fn("aau_bn_bwd_reduce")(_p(z), zp, _p(dy), dyp, _p(dpool), dpp, _p(dz), dzp, _p(scale), _p(shift),
-                                  _p(smean), _p(sinvstd), _p(red), N, H, W, Cc, relu, drop_p, drop_seed,
+                                  _p(smean), _p(sinvstd), _p(red), N, H, W, Cc, relu, drop_p, sp,
                                   _stream()), "aau_bn_bwd_reduce")
 
 
 def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, Cc, dy=None, dyp=0, scale=None,
                  shift=None, relu=1, drop_p=0.0, drop_seed=0):
+    sp, _keep = _seed_ptr(drop_seed, drop_p)
     check(fn("aau_bn_bwd_apply")(_p(z), zp, _p(dz), dzp, _p(gamma), _p(smean), _p(sinvstd), _p(red),
                                  _p(dgamma), _p(dbeta), M, Cc, _p(dy), dyp, _p(scale), _p(shift), relu, drop_p,
-                                 drop_seed, _stream()), "aau_bn_bwd_apply")
+                                 sp, _stream()), "aau_bn_bwd_apply")
 
 
 def bn_bwd_apply_conv1(z, zp, gamma, smean, sinvstd, red, dgamma, dbeta, N, H, W, Cc, dy, dyp, scale, shift, x, dw, ws,

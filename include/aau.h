@@ -159,11 +159,14 @@ int aau_bn_finalize(const float* stats, const float* gamma, const float* beta,
 int aau_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float* scale, float* shift, int C, float eps,
                      void* stream);
+/* Dropout masks are counter based: keep(m, c) = hash(*drop_seed, m*C + c) >= p.  drop_seed is */
+/* a DEVICE pointer (read only when drop_p > 0, may be NULL otherwise): the caller advances it  */
+/* on the stream once per step, so a step captured as a hipGraph draws a new mask per replay.  */
 /* y = relu?(z*scale+shift) [* dropout keep mask / (1-p)], optional broadcast of one     */
 /* source row per image (ASPP image-pool branch, pipeline:82).                           */
 int aau_bn_act(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pitch, const float* scale,
                const float* shift, int64_t M, int C, int relu, int64_t bcast_hw,
-               float drop_p, uint64_t drop_seed, void* stream);
+               float drop_p, const uint64_t* drop_seed, void* stream);
 /* y = relu(z*scale+shift) and p = MaxPool2d(2)(y) in one pass (encoder stages, :115-118)   */
 int aau_bn_act_pool(const aau_bf16* z, int z_pitch, aau_bf16* y, int y_pitch, aau_bf16* p, int p_pitch,
                     const float* scale, const float* shift, int N, int H, int W, int C, void* stream);
@@ -180,14 +183,14 @@ int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16* dy, int dy
                       const aau_bf16* dpool, int dpool_pitch, aau_bf16* dz, int dz_pitch,
                       const float* scale, const float* shift, const float* save_mean,
                       const float* save_invstd, float* red, int N, int H, int W, int C,
-                      int relu, float drop_p, uint64_t drop_seed, void* stream);
+                      int relu, float drop_p, const uint64_t* drop_seed, void* stream);
 /* Non-pooled layers may skip the intermediate: pass dz = NULL to the reduce pass and give */
 /* the apply pass dy (+ scale, shift, relu, dropout parameters); it recomputes the mask.   */
 int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
                      const float* gamma, const float* save_mean, const float* save_invstd,
                      const float* red, float* dgamma, float* dbeta, int64_t M, int C,
                      const aau_bf16* dy, int dy_pitch, const float* scale, const float* shift,
-                     int relu, float drop_p, uint64_t drop_seed, void* stream);
+                     int relu, float drop_p, const uint64_t* drop_seed, void* stream);
 
 /* First layer (pipeline:113 d1[0]): the apply pass fused with the weight gradient of its   */
 /* Conv2d(1, C, 3, pad 1) -- the layer has no input gradient, so dz is never written.     */

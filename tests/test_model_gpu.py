@@ -286,3 +286,31 @@ def test_benchmark_configuration_step_matches_oracle(A):
     for k in ("d1.0.block.1.running_mean", "d1.0.block.1.running_var", "u1.conv.1.block.1.running_mean",
               "u1.conv.1.block.1.running_var"):
         assert rel(sd_e[k], sd_o[k]) < 4e-2, k
+
+
+def test_dropout_draws_a_new_mask_every_step_also_under_graph_replay(A):
+    """The Dropout(0.1) of the ASPP projection (pipeline:78) is counter based with a DEVICE-resident seed that the
+    forward advances on the stream, so a training step captured as a hipGraph does not replay one frozen mask."""
+    from att_aspp_unet_amd import synth
+    torch.manual_seed(3)
+    m = A.AttentionASPPUNet(base_c=8).cuda().train()
+    assert m.bridge.project[3].p == 0.1
+    x, _ = synth.make_frames(2, 64, seed=4)
+    x = x.cuda()
+    with torch.no_grad():
+        a, b = m(x).clone(), m(x).clone()
+        assert not torch.equal(a, b)                           # eager: two steps, two masks
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+            out = m(x)
+        torch.cuda.current_stream().wait_stream(s)
+        g.replay(); r1 = out.clone()
+        g.replay(); r2 = out.clone()
+        torch.cuda.synchronize()
+        assert not torch.equal(r1, r2)
+        # and dropout is still dropout: ~10 % effect, not garbage
+        m.eval()
+        e = m(x)
+        assert float((r1 - r2).abs().max()) < 2.0 * float(e.abs().max()) + 1.0
