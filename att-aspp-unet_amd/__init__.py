@@ -9,7 +9,7 @@ from .model import ASPP, AttentionASPPUNet, AttentionGate, ConvBNReLU, DummyAtte
 from .losses import (ComboLoss, DiceLoss, EdgeLoss, TverskyLoss, build_criterion, iou_score,  # noqa: F401
                      seg_metrics)
 from .optim import FusedAdamW  # noqa: F401
-from .pipeline import (EARLY_STOP_PATIENCE, GRAD_CLIP, IMG_SIZE, SEED, WEIGHT_DECAY, GraphedForward, SyntheticLoader,  # noqa: F401
+from .pipeline import (EARLY_STOP_PATIENCE, GRAD_CLIP, IMG_SIZE, SEED, WEIGHT_DECAY, GraphedForward, GraphedTrainStep, SyntheticLoader,  # noqa: F401
                        TrainStep, evaluate, get_args, load_state_dict_compat, lr_at_epoch, predict_prob_tta, predict_sliding_window, set_seed,
                        train)
 from .parallel import DataParallel, GradBucketReducer, bucket_ranges  # noqa: F401

@@ -105,7 +105,31 @@ class _Rec:
         finally:
             trav(0)
 
-    def _run(self, stream: int):
+    def segments(self):
+        """The launch list cut at its callbacks: [(ops, callback or None), ...].  Used to replay the backward as one
+        hipGraph per segment with the gradient-bucket all-reduces issued in between (pipeline.GraphedTrainStep)."""
+        out, cur = [], []
+        for op in self.ops:
+            if op[0] is None and op[2] == "callback":
+                out.append((cur, op[1]))
+                cur = []
+            else:
+                cur.append(op)
+        out.append((cur, None))
+        return out
+
+    def run_ops(self, ops_, stream: int, first: bool, last: bool):
+        """One segment of ``segments()``.  The traversal parity (aau_traverse) runs on across the segments."""
+        trav = _abi.fn("aau_traverse")
+        if first:
+            trav(0 if _NO_TRAVERSE else 1)
+        try:
+            self._run(stream, ops_)
+        finally:
+            if last:
+                trav(0)
+
+    def _run(self, stream: int, ops_=None):
         side_t = side = None
         if self.uses_side:
             if self.side is None:
@@ -113,7 +137,7 @@ class _Rec:
             side_t = self.side
             side = side_t.cuda_stream
             main_t = torch.cuda.current_stream()
-        for f, a, name, sid in self.ops:
+        for f, a, name, sid in (self.ops if ops_ is None else ops_):
             if f is None:
                 if name == "fork":
                     if side_t is not None:
@@ -674,15 +698,18 @@ class Plan:
         self.fwd.run(stream)
         return self.logits
 
-    def run_backward(self, dlogits: torch.Tensor | None):
-        stream = torch.cuda.current_stream().cuda_stream
+    def begin_backward(self, dlogits: torch.Tensor | None = None):
         st = self.eng.store
         if dlogits is not None and dlogits.data_ptr() != self.dlogits.data_ptr():
             self.dlogits.copy_(dlogits.reshape(self.dlogits.shape), non_blocking=True)
         self.red_arena.buf.zero_()
         st.gflat.zero_()
+
+    def run_backward(self, dlogits: torch.Tensor | None):
+        stream = torch.cuda.current_stream().cuda_stream
+        self.begin_backward(dlogits)
         self.bwd.run(stream)
-        st.bind_grads()
+        self.eng.store.bind_grads()
 
 
 class Engine:

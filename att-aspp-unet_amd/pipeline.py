@@ -226,6 +226,79 @@ class TrainStep:
         return self.loss[0]
 
 
+class GraphedTrainStep:
+    """``TrainStep`` replayed as hipGraphs.  Without data parallelism the whole step is one graph.  With it, the backward
+    launch list is cut at the gradient-bucket marks: one graph per segment, and the RCCL all-reduce of a bucket is
+    issued (eagerly, on its own stream) between two graph launches -- the collectives are not captured, the ~290 kernel
+    launches of the step are.  (Measured on one MI355X with world size 1: the segmented form is 1 % slower than the
+    eager launch list, which itself is within 1 % of the single graph, so bench.py keeps N > 1 eager.)  Inputs are copied into static buffers, so any ``(x, y)`` of the captured shape works.
+    The learning rate is a launch argument: re-create the object when the scheduler changes it (once per epoch)."""
+
+    def __init__(self, step: "TrainStep", x, y, warmup: int = 2):
+        self.step = step
+        m, dp = step.model, step.dp
+        assert m.training
+        self.x, self.y = x.clone(), y.clone()
+        for _ in range(max(warmup, 1 if step.sums is None else 0)):   # plan, optimiser state, allocator pools
+            step(self.x, self.y)
+        torch.cuda.synchronize()
+        plan = m._plan_for(self.x)
+        B, _, H, W = self.x.shape
+        segs = plan.bwd.segments()
+        if dp is None:
+            assert all(cb is None for _, cb in segs)
+        inv = 1.0 if dp is None else dp.inv_scale
+
+        def head():
+            logits = plan.run_forward(self.x)
+            ops.criterion(logits, self.y, step.sums, step.loss, plan.dlogits, B, H, W, step.finetune, step.neg_w,
+                          step.edge_w)
+            plan.begin_backward()
+
+        def seg(k):
+            plan.bwd.run_ops(segs[k][0], torch.cuda.current_stream().cuda_stream, first=(k == 0), last=(k == len(segs) - 1))
+
+        parts = []                                   # [(callables, callback after them)]
+        for k, (_, cb) in enumerate(segs):
+            fns = ([head] if k == 0 else []) + [lambda k=k: seg(k)]
+            parts.append((fns, cb))
+        if dp is None:
+            parts[-1][0].append(lambda: step.opt.step(inv_scale=inv))
+            self.tail = None
+        else:
+            self.tail = self._capture([lambda: step.opt.step(inv_scale=inv)])
+        # a segment with nothing to launch (the list ends with a mark) is not captured
+        self.parts = [(self._capture(fns) if (k == 0 or segs[k][0] or len(fns) > 1) else None, cb)
+                      for k, (fns, cb) in enumerate(parts)]
+        m.engine.store.bind_grads()
+
+    @staticmethod
+    def _capture(fns):
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.cuda.graph(g, stream=s):
+            for fn in fns:
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        return g
+
+    def __call__(self, x, y):
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        if y.data_ptr() != self.y.data_ptr():
+            self.y.copy_(y, non_blocking=True)
+        for g, cb in self.parts:
+            if g is not None:
+                g.replay()
+            if cb is not None:
+                cb()
+        if self.tail is not None:
+            self.step.dp.finish()
+            self.tail.replay()
+        return self.step.loss[0]
+
+
 def get_args(argv=None):
     """pipeline:539-550 (train / predict / calibrate flags), plus --synthetic_batches / --img_size."""
     p = argparse.ArgumentParser("A-ASPP-UNet unified (MI355X)")

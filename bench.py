@@ -135,19 +135,15 @@ def main():
     for i in range(a.warmup):
         loss = run(x, y)
     barrier()
-    if a.graph and world == 1 and dp is None:
+    if a.graph and (dp is None or os.environ.get("AAU_BENCH_DP_GRAPH") == "1"):
+        # the whole step as ONE hipGraph at N = 1.  With data parallelism GraphedTrainStep can replay one graph per
+        # gradient-bucket segment of the backward with the RCCL all-reduces in between, but that measured 1 % SLOWER
+        # than the eager launch list (which already runs within 1 % of the single graph), so N > 1 stays eager.
         try:
-            g = torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step(x, y)
-                with torch.cuda.graph(g, stream=s):
-                    gl = step(x, y)
-            torch.cuda.current_stream().wait_stream(s)
-            g.replay()
+            gstep = A.GraphedTrainStep(step, x, y, warmup=0)
+            gstep(x, y)
             torch.cuda.synchronize()
-            run = lambda *_: (g.replay(), gl)[1]
+            run = gstep
             graphed = True
         except Exception as e:  # capture is an optimisation; the eager replay list is the same work
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing the eager launch list",

@@ -82,3 +82,44 @@ def test_data_parallel_wiring_single_rank_matches_plain_step(A, golden):
         assert abs(float(g0.norm()) - float(g2.norm())) < (4 * noise_norm + 0.01) * float(g0.norm())
     finally:
         dist.destroy_process_group()
+
+
+def test_graphed_train_step_segments_match_eager_with_and_without_data_parallel(A, golden):
+    """GraphedTrainStep: one hipGraph (no DP) / one graph per gradient-bucket segment with the RCCL all-reduces issued
+    in between (world size 1 here) must train like the eager TrainStep."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29518")
+    g = golden("g4_trained_c8_128.npz")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    args = Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05)
+    x, y = torch.from_numpy(g["x"][:4]).cuda(), torch.from_numpy(g["y"][:4]).cuda()
+
+    def run(use_dp, graphed, steps=6):
+        m = A.AttentionASPPUNet(base_c=8)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        m.bridge.project[3].p = 0.0
+        dp = A.DataParallel(m) if use_dp else None
+        step = A.TrainStep(m, A.FusedAdamW(m, lr=1e-3), args, dp)
+        fn = A.GraphedTrainStep(step, x, y, warmup=0) if graphed else step
+        skip = 1 if graphed else 0                   # the graphed form ran one eager step to build its state
+        losses = [float(fn(x, y).item()) for _ in range(steps - skip)]
+        if use_dp:
+            assert not dp.reducer.works
+        return losses, torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        le, we = run(False, False)
+        for use_dp in (False, True):
+            lg, wg = run(use_dp, True)
+            assert len(lg) == len(le) - 1
+            for a_, b_ in zip(lg, le[1:]):
+                assert a_ == pytest.approx(b_, rel=2e-3), (lg, le)
+            assert le[-1] < le[0]
+            cos = float(torch.dot(wg - we, wg - we) ** 0.5 / we.norm())
+            assert cos < 5e-3, cos                  # same weights after 6 Adam steps, up to the atomics' run-to-run spread
+    finally:
+        dist.destroy_process_group()
