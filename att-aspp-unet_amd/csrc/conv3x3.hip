@@ -979,6 +979,278 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same persistent resident-weight structure for the 1x1 convolutions of the decoder at high resolution
+// (ConvTranspose2d(2,2) forward as a GEMM with the pixel-shuffle store, the attention-gate Wg / Wx convs and their
+// accumulating input gradients): K is 1-3 steps there, and the generic implicit-GEMM kernel spends its time in
+// per-tile prologues, three exposed load waits and barriers (a no-store ablation of it still took 73 % of the
+// time).  Here the weights ([BQ][Cpad], <= 36 KB) stay in LDS, the activation tile of the next 256 pixels is in
+// flight while the current one is multiplied, and there is one barrier per 32-channel chunk.
+template <int BQ, int NW>
+__global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, int npatch) {
+    constexpr int BK = 32, HW_ = 16, HROWS = HW_ * HW_, HPAD = 256, NI = BQ / 16, MI = 16 / NW, HL = 16 / NW;
+    constexpr int HALO_E = HPAD * BK, WT_E = BQ * BK;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];   // [2 pixel tiles][nchunk weight tiles]
+    auto sH = [&](int b) -> unsigned short* { return dsm + b * HALO_E; };
+    auto sWt = [&](int chunk) -> unsigned short* { return dsm + 2 * HALO_E + chunk * WT_E; };
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int q0 = blockIdx.y * BQ;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+
+    // ---- weights: all (chunk, tap) tiles of this channel tile, once ----
+    {
+        const int ntile = a.nchunk;
+        constexpr int PIECES = BQ * 4;                        // 16-B pieces per tile
+        for (int base = 0; base < ntile * PIECES; base += 64 * NW) {   // uniform trip count; wave-linear 1 KiB pieces
+            const int p = base + tid;
+            const int tile = p / PIECES, r = p - tile * PIECES;
+            const int row = r >> 2, lc = swz32(row, r & 3);
+            const int chunk = tile;
+            const bool ok = tile < ntile && q0 + row < d.Cout;
+            const unsigned v = ok ? (unsigned)(((q0 + row) * d.Cpad + chunk * BK + lc * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dsm + 2 * HALO_E + (base + wave * 64) * 8), 16, (int)v, 0, 0, 0);
+        }
+    }
+    // ---- halo roles (patch independent part) ----
+    int hy_[HL], hx_[HL], lc_[HL];
+    bool htail[HL];
+    const int tail_c0 = (a.nchunk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+        const int hr = (i * NW + wave) * 16 + (lane >> 2);
+        lc_[i] = swz32(hr, lane & 3);
+        hy_[i] = hr < HROWS ? hr / HW_ : -100000;
+        hx_[i] = hr % HW_;
+        htail[i] = tail_c0 + lc_[i] * 8 < d.Cin;
+    }
+    const bool has_tail = d.Cpad != d.Cin;
+    auto patch_origin = [&](int patch, int& n, int& y0, int& x0) {
+        if (a.rev) patch = npatch - 1 - patch;
+        const int px_t = patch % a.tiles_x;
+        const int t2 = patch / a.tiles_x;
+        const int py_t = t2 % a.tiles_y;
+        n = t2 / a.tiles_y; y0 = py_t * 16; x0 = px_t * 16;
+    };
+    auto issue_halo = [&](int buf, int patch, int chunk) {
+        int n, y0, x0;
+        patch_origin(patch, n, y0, x0);
+        const bool last = has_tail && chunk == a.nchunk - 1;
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+            const int y = y0 + hy_[i], x = x0 + hx_[i];
+            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
+            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * NW + wave) * 16 * BK), 16, (int)v,
+                                                     chunk * BK * 2, 0, 0);
+        }
+    };
+
+    constexpr bool STATS = true;
+    constexpr int NS = STATS ? NI : 1;
+    const bool want_stats = STATS && a.stats != nullptr;
+    float s1[NS][4], s2[NS][4];
+#pragma unroll
+    for (int ni = 0; ni < NS; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+
+    const int first = blockIdx.x, stride = gridDim.x;
+    const bool full_tiles = q0 + BQ <= d.Cout;   // every lane issues all NI*MI stores of a patch
+    int t = 0;
+    if (first < npatch) issue_halo(0, first, 0);
+    for (int patch = first; patch < npatch; patch += stride) {
+        f32x4 acc[NI][MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < a.nchunk; ++chunk, ++t) {
+            // halo(t) (and, the first time, the weights) must have landed.  At the first chunk of a later
+            // patch the only younger operations are the previous patch's NI*MI output stores per lane
+            // (vmcnt retires in issue order), which may stay in flight.
+            if (t > 0 && chunk == 0 && full_tiles) {
+                if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            {   // prefetch the next (patch, chunk) tile into the other buffer
+                int np = patch, nc = chunk + 1;
+                if (nc == a.nchunk) { nc = 0; np += stride; }
+                if (np < npatch) issue_halo((t + 1) & 1, np, nc);
+            }
+            const unsigned short* hbase = sH(t & 1);
+            {
+                constexpr int ty = 0, tx = 0;
+                const unsigned short* wbase = sWt(chunk);
+                bf16x8 wf[NI], af[MI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = ni * 16 + fr;
+                    wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
+                    af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
+                }
+#ifdef AAU_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#ifdef AAU_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+        }
+        // ---- per-patch epilogue ----
+        int n, y0, x0;
+        patch_origin(patch, n, y0, x0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int y = y0 + wave * MI + mi, x = x0 + fr;
+            const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int q = q0 + ni * 16 + 4 * fk;
+                if (q >= d.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+                if constexpr (STATS) {
+                    if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
+                }
+                // per-channel vectors are indexed by the real output channel (co for the pixel-shuffle store)
+                const int Co = d.Cout >> 2;
+                const int qv = d.shuffle2x2 ? q % Co : q;
+                if (a.bias) {
+                    const f32x4 b = *(const f32x4*)(a.bias + qv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b[r];
+                }
+                if (a.scale) {
+                    const f32x4 sc = *(const f32x4*)(a.scale + qv);
+                    const f32x4 sh = *(const f32x4*)(a.shift + qv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+                }
+                unsigned short* out;
+                if (d.shuffle2x2) {   // ConvTranspose2d(2,2): row q = (pos, co) goes to sub-pixel pos of the 2x grid
+                    const int pos = q / Co;
+                    const int64_t op = ((int64_t)n * (2 * d.H) + (2 * y + (pos >> 1))) * (2 * d.W) + (2 * x + (pos & 1));
+                    out = a.dst + op * d.dst_pitch + qv;
+                } else {
+                    out = a.dst + pixel * d.dst_pitch + q;
+                }
+                if (d.accumulate) {
+                    const u32x2 old = *(const u32x2*)out;
+                    v[0] += __uint_as_float(old[0] << 16);
+                    v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(old[1] << 16);
+                    v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                }
+                if (d.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                u32x2 pk;
+                pk[0] = pack2(v[0], v[1]);
+                pk[1] = pack2(v[2], v[3]);
+                *(u32x2*)out = pk;
+            }
+        }
+    }
+    if (want_stats) {
+        float* sst = (float*)dsm;   // halo buffers are dead
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < 2 * BQ) sst[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NS; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0) {
+                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
+                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                }
+            }
+        }
+        __syncthreads();
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        if (tid < 2 * BQ) {
+            const int which = tid / BQ, ql = tid - which * BQ;
+            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        }
+    }
+}
+
+
+// true when the resident-weight 1x1 kernel applies (high-resolution 1x1 convs with a small weight matrix)
+bool conv1x1_resw_applicable(const aau_conv_desc* d, bool want_stats) {
+    (void)want_stats;
+    if (!(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo &&
+          d->H % 16 == 0 && d->W % 16 == 0 && d->Cpad % 32 == 0))
+        return false;
+    if (getenv("AAU_NO_PW_RESW")) return false;
+    const int BQ = d->Cout <= 48 ? 48 : 96;
+    const int ntq = (d->Cout + BQ - 1) / BQ;
+    const int64_t npatch = (int64_t)d->N * (d->H / 16) * (d->W / 16);
+    // one patch per workgroup gains nothing from residency: 1024 patches, or 512 when there are several channel
+    // tiles (the ConvTranspose GEMMs: -20 % on u2.up; the 96-channel gate convs at 512 patches were 5-20 % slower)
+    int minp = ntq >= 2 ? 512 : 1024;
+    if (const char* e = getenv("AAU_PW_MINPATCH")) minp = atoi(e);   // experiment
+    return npatch >= minp && ntq <= 4 && (size_t)(d->Cpad / 32) * BQ * 64 <= 48 * 1024;
+}
+
+int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
+                        const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
+                        hipStream_t s) {
+    C3Args a;
+    a.d = *d;
+    a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
+    a.bn_z = nullptr; a.bn_zp = 0; a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr;
+    a.rev = next_traversal();
+    a.nchunk = d->Cpad / 32;
+    a.src_bytes = src_bytes;
+    a.wpk_bytes = wpk_bytes;
+    a.tiles_x = d->W / 16;
+    a.tiles_y = d->H / 16;
+    const int BQ = d->Cout <= 48 ? 48 : 96;      // a 192-channel tile (activations read once) measured no faster
+    const int ntq = (d->Cout + BQ - 1) / BQ;
+    const int npatch = a.tiles_x * a.tiles_y * d->N;
+    const size_t wbytes = ((size_t)a.nchunk * BQ * 64 + 8191) / 8192 * 8192;   // whole staging rounds of 512 threads
+    const size_t lds = (size_t)2 * 256 * 64 + wbytes;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)conv1x1_resw_kernel<48, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)conv1x1_resw_kernel<96, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    if (const char* e = getenv("AAU_PW_PERCU")) per_cu = atoi(e);   // experiment
+    int gx = 256 * per_cu / ntq;
+    if (gx > npatch) gx = npatch;
+    if (gx < 1) gx = 1;
+    if (BQ == 48) hipLaunchKernelGGL((conv1x1_resw_kernel<48, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
+    else hipLaunchKernelGGL((conv1x1_resw_kernel<96, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
+    return check_launch("aau_conv_igemm(1x1 resident weights)");
+}
+
 // true when the halo kernel applies to this descriptor
 bool conv3x3_applicable(const aau_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->shuffle2x2 &&

@@ -361,6 +361,11 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
                    const BnRedArgs* bn, hipStream_t s);
 
+bool conv1x1_resw_applicable(const aau_conv_desc* d, bool want_stats);
+int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
+                        const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
+                        hipStream_t s);
+
 template <int BK, int BQ, bool SMALL = false>
 static int launch(const IgemmArgs& a, hipStream_t s) {
     constexpr int BP = SMALL ? 64 : ((BQ == 96) ? 128 : 256);
@@ -418,6 +423,8 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
         return conv3x3_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, bn,
                               (hipStream_t)stream);
     AAU_REQUIRE(!bn, "aau_conv_igemm_bnred: only the halo-tiled 3x3 path carries the fused reduce (aau_conv_is_halo3x3)");
+    if (conv1x1_resw_applicable(d, stats != nullptr))
+        return conv1x1_resw_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, (hipStream_t)stream);
     a.rev = next_traversal();
     const bool narrow = d->Cout <= 48;
     // long-K, few-tile problems (bridge at 32x32): halve the pixel tile to double the workgroup count

@@ -129,6 +129,64 @@ def test_igemm_epilogue_bias_affine_relu_accumulate_pitch(ops):
     assert float(got[..., :16].abs().max()) == 0 and float(got[..., 16 + Cout:].abs().max()) == 0  # neighbours untouched
 
 
+@pytest.mark.parametrize("case", [(4, 256, 256, 96, 48), (4, 256, 256, 40, 104), (5, 256, 240, 192, 96)])
+def test_resident_weight_1x1_path(ops, case):
+    """>= 1024 patches of 16x16 and a small weight matrix: 1x1 convs take the persistent resident-weight kernel.
+    Forward with BN statistics, strided source / destination pitches, then bias + affine + ReLU + accumulate."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    xw = R.bf16_round(torch.randn(N, H, W, Cin + 8, generator=g))
+    x = xw[..., 8:]
+    w = R.bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5)
+    raw = R.conv_fwd(x, w)
+    cpad = ops.cpad_of(Cin)
+    xd, wd = dev(xw.to(torch.bfloat16)), dev(pack_fwd(w, cpad))
+    wide = torch.zeros(N, H, W, Cout + 16, dtype=torch.bfloat16, device="cuda")
+    d = ops.conv_desc(N, H, W, Cin, Cin + 8, H, W, Cout, Cout + 16, Cpad=cpad)
+    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    ops.conv_igemm(d, xd[..., 8:], wd, wide[..., 8:], stats=stats)
+    torch.cuda.synchronize()
+    got = wide.cpu()
+    assert rel_err(got[..., 8:8 + Cout], raw) < 6e-3
+    assert float(got[..., :8].abs().max()) == 0 and float(got[..., 8 + Cout:].abs().max()) == 0
+    flat = raw.reshape(-1, Cout)
+    st = stats.sum(0).cpu()
+    assert float((st[0] - flat.sum(0)).abs().max()) < 2e-3 * float(flat.abs().sum(0).max())
+    assert torch.allclose(st[1], (flat ** 2).sum(0), rtol=2e-3)
+    # epilogue: bias, affine, ReLU, accumulate into the existing destination
+    bias, scale, shift = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    prev = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    ref = torch.relu((raw + bias) * scale + shift + prev)
+    wide.zero_()
+    wide[..., 8:8 + Cout] = dev(prev.to(torch.bfloat16))
+    d2 = ops.conv_desc(N, H, W, Cin, Cin + 8, H, W, Cout, Cout + 16, Cpad=cpad, accumulate=1, relu=1)
+    ops.conv_igemm(d2, xd[..., 8:], wd, wide[..., 8:], bias=dev(bias), scale=dev(scale), shift=dev(shift))
+    torch.cuda.synchronize()
+    got = wide.cpu()
+    assert rel_err(got[..., 8:8 + Cout], ref) < 8e-3
+    assert float(got[..., :8].abs().max()) == 0 and float(got[..., 8 + Cout:].abs().max()) == 0
+
+
+def test_resident_weight_convT_shuffle_path(ops):
+    """ConvTranspose2d(2,2) forward at a resolution that takes the resident-weight 1x1 kernel (pixel-shuffle store)."""
+    N, H, W, Ci, Co = 4, 256, 256, 96, 48
+    g = torch.Generator().manual_seed(31)
+    x = R.bf16_round(torch.randn(N, H, W, Ci, generator=g))
+    w = R.bf16_round(torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5)  # IOHW
+    b = torch.randn(Co, generator=g)
+    ref = R.convT_fwd(x, w, b)
+    cpad = ops.cpad_of(Ci)
+    wp = torch.zeros(4 * Co, 1, cpad)
+    wp[:, 0, :Ci] = w.permute(2, 3, 1, 0).reshape(4 * Co, Ci)
+    d = ops.conv_desc(N, H, W, Ci, Ci, H, W, 4 * Co, 2 * Co, Cpad=cpad, shuffle2x2=1)
+    wide = torch.zeros(N, 2 * H, 2 * W, 2 * Co, dtype=torch.bfloat16, device="cuda")
+    ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(wp.to(torch.bfloat16)), wide[..., Co:], bias=dev(b))
+    torch.cuda.synchronize()
+    got = wide.cpu()
+    assert rel_err(got[..., Co:], ref) < 6e-3
+    assert float(got[..., :Co].abs().max()) == 0
+
+
 def test_halo3x3_epilogue_bias_affine_relu_accumulate_pitch(ops):
     N, H, W, Cin, Cout = 2, 16, 32, 40, 56
     g = torch.Generator().manual_seed(55)
