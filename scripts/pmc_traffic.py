@@ -8,10 +8,10 @@
 Units / corrections as the guide prescribes: both counters tick in KiB; on gfx950 FETCH_SIZE reports half of the
 bytes of wide coalesced streaming reads (128-B requests tallied at 64 B), so it is doubled; WRITE_SIZE is exact for
 16-B-per-lane stores and float atomics.  The last full step (between two pack_kernel launches) is summed; "conv"
-launches are the MFMA implicit-GEMM kernels (igemm / conv3x3* / wgrad* and the split-K reduce)."""
+launches are the MFMA implicit-GEMM kernels (igemm / conv3x3* / conv1x1* / wgrad* and the split-K reduce)."""
 import csv, glob, json, os, sys
 
-CONV = ("igemm_kernel", "conv3x3", "wgrad", "wg_reduce")
+CONV = ("igemm_kernel", "conv3x3", "conv1x1", "wgrad", "wg_reduce")
 
 
 def last_step(d, counter):
