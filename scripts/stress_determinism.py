@@ -33,4 +33,30 @@ tot += run_case("igemm dil6 32x32 384->768", 8, 32, 32, 384, 768, 3, 6)
 tot += run_case("igemm SMALL dgrad-like 768->384 d12", 8, 32, 32, 768, 384, 3, 12)
 tot += run_case("igemm 1x1 3840->768", 8, 32, 32, 3840, 768, 1, 1)
 tot += run_case("igemm 1x1 96->48 256", 8, 256, 256, 96, 48, 1, 1, reps=12)
+
+
+def run_wgrad(name, N, H, W, Ci, Co, k, dil, reps=12):
+    """split-K through slabs: bitwise reproducible by construction; the screen repeats it under changing traffic"""
+    x = torch.randn(N, H, W, Ci, device="cuda").to(torch.bfloat16)
+    dz = torch.randn(N, H, W, Co, device="cuda").to(torch.bfloat16)
+    d = ops.conv_desc(N, H, W, Ci, Ci, H, W, Co, Co, k, k, 1, dil * (k // 2), dil)
+    ws = torch.full((ops.conv_wgrad_ws_bytes(d) // 4,), float("nan"), device="cuda")
+    other = torch.randn(64 << 20, device="cuda")
+    outs = []
+    for r in range(reps):
+        dw = torch.zeros(Co, k * k, Ci, device="cuda")
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_wgrad(d, x, dz, dw, ws)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    bad = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0]).sum())}", flush=True)
+    return bad
+
+
+tot += run_wgrad("wgrad3x3 512 48->48", 8, 512, 512, 48, 48, 3, 1)
+tot += run_wgrad("wgrad3x3 64 768->384", 8, 64, 64, 768, 384, 3, 1)
+tot += run_wgrad("wgrad 1x1 256 96->48", 8, 256, 256, 96, 48, 1, 1)
+tot += run_wgrad("wgrad dil6 32 384->768", 8, 32, 32, 384, 768, 3, 6)
 print("TOTAL mismatches", tot)
