@@ -194,6 +194,21 @@ def main():
                 "ms_per_step_by_family": {k: v["ms"] / nprof for k, v in prof.items()},
                 "counted_flops_per_step": {k: v["flops"] / nprof for k, v in prof.items()},
                 "whole_step_frac": alg / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS}
+    # The reference loop hands HOST batches to the device every step (pipeline:319: 2 x 8 MB at bs 8).  `value` is
+    # measured with the inputs resident in HBM; this extra pass times the same steps with a pinned-host -> HBM copy of
+    # the frames and the masks issued in front of each step (same stream: the worst case, no prefetch overlap).
+    h2d = None
+    if rank == 0 and world == 1 and not a.no_roofline:
+        xh, yh = x.cpu().pin_memory(), y.cpu().pin_memory()
+        nh = max(5, a.steps // 2)
+        for _ in range(2):
+            x.copy_(xh, non_blocking=True); y.copy_(yh, non_blocking=True); run(x, y)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nh):
+            x.copy_(xh, non_blocking=True); y.copy_(yh, non_blocking=True); run(x, y)
+        torch.cuda.synchronize()
+        h2d = a.batch * nh / (time.perf_counter() - t1)
     if world > 1:
         dist.barrier()
 
@@ -212,7 +227,7 @@ def main():
                                    f"base_c {a.base_c}, 1x{a.size}x{a.size}, batch {a.batch}/GPU, bf16 activations, "
                                    f"fp32 master weights" + (", RCCL grad all-reduce overlapped with backward" if world > 1 else ""),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
-                       "final_loss": loss_val},
+                       "final_loss": loss_val, "images_per_sec_with_h2d_of_inputs": h2d},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
