@@ -48,6 +48,8 @@ U64 = C.c_uint64
 _SIGS = {
     "aau_prof_enable": [I],
     "aau_prof_collect": [P, P, P],
+    "aau_prof_collect_launches": [I, P, P, P, P, P, P],
+    "aau_prof_label": [C.c_char_p],
     "aau_conv_igemm": [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P],
     "aau_conv_is_halo3x3": [C.POINTER(ConvDesc)],
     "aau_traverse": [I],
@@ -84,8 +86,11 @@ _SIGS = {
     "aau_bn_bwd_apply_rank1": [P, I, P, I, P, P, P, P, P, P, L, I, P, P, P, P, P],
     "aau_criterion": [P, P, P, P, P, I, I, I, I, F, F, F, P],
     "aau_seg_metrics": [P, P, P, P, I, I, I, F, P],
+    "aau_seg_counts": [P, I, P, I, L, P, P],
+    "aau_loss_terms": [P, P, P, P, P, I, I, I, C.POINTER(C.c_float), P],
     "aau_grad_sqnorm": [P, L, F, P, P],
     "aau_adamw_step": [P, P, P, P, L, P, P, F, F, F, F, F, F, F, P],
+    "aau_adamw_step_dev": [P, P, P, P, L, P, P, P, P, I, F, F, F, F, F, P],
     "aau_f32_to_bf16": [P, P, L, P],
     "aau_bf16_to_f32": [P, P, L, P],
     "aau_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
@@ -135,8 +140,27 @@ def fn(name: str):
     return getattr(lib(), name)
 
 
+PROF_ON = False   # mirrors aau_prof_enable: the engine then names every launch (aau_prof_label)
+
+
 def prof_enable(on: bool) -> None:
+    global PROF_ON
     check(lib().aau_prof_enable(1 if on else 0), "aau_prof_enable")
+    PROF_ON = bool(on)
+
+
+def prof_collect_launches(cap: int = 8192) -> list:
+    """-> [{tag, ms, flops, bytes, family}] in issue order (clears the records)."""
+    n = C.c_int(0)
+    tags = C.create_string_buffer(cap * 96)
+    ms, fl, by = (C.c_double * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+    fam = (C.c_int * cap)()
+    check(lib().aau_prof_collect_launches(cap, C.byref(n), tags, ms, fl, by, fam), "aau_prof_collect_launches")
+    out = []
+    for i in range(n.value):
+        label, _, t = tags.raw[i * 96:(i + 1) * 96].split(b"\0", 1)[0].decode().partition("|")
+        out.append({"label": label, "tag": t, "ms": ms[i], "flops": fl[i], "bytes": by[i], "family": PROF_NAMES[fam[i]]})
+    return out
 
 
 def prof_collect() -> dict:

@@ -117,6 +117,9 @@ int next_traversal();   // 1: this launch walks its tensors from the end (aau_tr
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// names the kernel variant a launcher picked (and its algorithmic HBM bytes) on the live ProfScope of this thread
+void prof_tag(const char* tag, double bytes = 0.0);
+
 struct ProfScope {  // brackets one launch with events when profiling is on
     ProfScope(int family, double flops, hipStream_t s);
     ~ProfScope();

@@ -1246,6 +1246,7 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     int gx = 256 * per_cu / ntq;
     if (gx > npatch) gx = npatch;
     if (gx < 1) gx = 1;
+    prof_tag(BQ == 48 ? "conv1x1_resw<48>" : "conv1x1_resw<96>");
     if (BQ == 48) hipLaunchKernelGGL((conv1x1_resw_kernel<48, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
     else hipLaunchKernelGGL((conv1x1_resw_kernel<96, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
     return check_launch("aau_conv_igemm(1x1 resident weights)");
@@ -1294,6 +1295,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                     hipFuncSetAttribute((const void*)conv3x3_resw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     attr2 = true;
                 }
+                prof_tag("conv3x3_resw2");
                 hipLaunchKernelGGL(conv3x3_resw2_kernel, dim3(gx2, 1), dim3(512), lds2, s, a, npatch);
                 return check_launch("aau_conv_igemm(3x3 resident weights, two patch streams)");
             }
@@ -1313,6 +1315,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
             const int gx = npatch < 256 / ntq ? npatch : 256 / ntq;
             // 8 waves on one patch (2 per SIMD): -10...20 % against 4 waves on every layer that takes this path
             const bool w8 = getenv("AAU_RESW_W4") == nullptr;
+            prof_tag(narrow ? "conv3x3_resw<48>" : "conv3x3_resw<96>");
             if (narrow && w8) hipLaunchKernelGGL((conv3x3_resw_kernel<48, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
             else if (narrow) hipLaunchKernelGGL((conv3x3_resw_kernel<48, 4>), dim3(gx, ntq), dim3(256), lds, s, a, npatch);
             else if (w8) hipLaunchKernelGGL((conv3x3_resw_kernel<96, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
@@ -1326,6 +1329,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     if (wide_patch) a.tiles_x = d->W / 32;
     const int64_t grid = (int64_t)((d->Cout + BQ - 1) / BQ) * a.tiles_x * a.tiles_y * d->N;
     if (grid <= 0 || grid > 0x7fffffff) { set_error("conv3x3: grid out of range"); return AAU_E_INVALID; }
+    prof_tag(narrow ? "conv3x3g<48>" : "conv3x3g<96>");
     if (!wide_patch && !getenv("AAU_C3_NOGROUP")) {
         if (narrow) hipLaunchKernelGGL((conv3x3g_kernel<48>), dim3((unsigned)grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv3x3g_kernel<96>), dim3((unsigned)grid), dim3(256), 0, s, a);

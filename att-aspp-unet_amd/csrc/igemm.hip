@@ -376,6 +376,11 @@ static int launch(const IgemmArgs& a, hipStream_t s) {
         set_error("aau_conv_igemm: grid %lld out of range", (long long)grid);
         return AAU_E_INVALID;
     }
+    {
+        char tag[AAU_PROF_TAG_LEN];
+        snprintf(tag, sizeof(tag), "igemm<%d,%d,%d>%s", BK, BQ, SMALL ? 1 : 0, a.d.KH * a.d.KW > 1 ? (a.d.dil > 1 ? " dilated" : " taps") : "");
+        prof_tag(tag);
+    }
     hipLaunchKernelGGL((igemm_kernel<BK, BQ, SMALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return check_launch("aau_conv_igemm");
 }
@@ -418,6 +423,9 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
     a.nchunk = d->Cpad / (bk64 ? 64 : 32);
     const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
     ProfScope prof(0, flops, (hipStream_t)stream);
+    // algorithmic HBM bytes: every input / output element and every weight once (bf16)
+    prof_tag(nullptr, 2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout * (d->accumulate ? 2 : 1) +
+                             (double)d->Cout * d->KH * d->KW * d->Cin));
     a.rev = 0;
     if (conv3x3_applicable(d))
         return conv3x3_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, bn,

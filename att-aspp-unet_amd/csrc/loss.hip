@@ -199,6 +199,92 @@ __global__ __launch_bounds__(256) void crit_grad_kernel(const float* logits, con
     dlogits[(int64_t)b * H * W + (int64_t)y * W + x] = g * loss_scale;
 }
 
+// ---- the loss classes used on their own (pipeline:173-189 DiceLoss / TverskyLoss / ComboLoss, :196-216 EdgeLoss) ----
+// Every sample counts (no positive-subset selection: that belongs to build_criterion):
+//   total = w_ratio * mean_b (1 - N_b / D_b) + w_bce * mean(bce) + w_edge * mean |grad p - grad t|
+//   N_b = nu * tp_b + s_n,   D_b = d_tp * tp_b + d_p * sum p_b + d_t * sum t_b + s_d      (tp = sum p*t)
+// Dice(smooth s): nu 2, s_n s, d_tp 0, d_p 1, d_t 1, s_d s.  Tversky(a, b, s): nu 1, s_n s, d_tp 1-a-b, d_p a, d_t b, s_d s.
+struct TermCoef { float w_ratio, nu, s_n, d_tp, d_p, d_t, s_d, w_bce, w_edge; };
+
+__global__ void terms_loss_kernel(const float* sums, float* loss_out, int B, float HW, TermCoef k) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ratio = 0.f, bce = 0.f, edge = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* s = sums + b * NS;
+        ratio += 1.f - (k.nu * s[2] + k.s_n) / (k.d_tp * s[2] + k.d_p * s[1] + k.d_t * s[0] + k.s_d);
+        bce += s[3];
+        edge += s[4];
+    }
+    const float inv_all = 1.f / ((float)B * HW);
+    ratio = k.w_ratio * ratio / (float)B;
+    bce *= k.w_bce * inv_all;
+    edge *= k.w_edge * inv_all;
+    loss_out[0] = ratio + bce + edge;
+    loss_out[1] = ratio;
+    loss_out[2] = bce;
+    loss_out[3] = edge;
+}
+
+__global__ __launch_bounds__(256) void terms_grad_kernel(const float* logits, const float* targets, const float* sums,
+                                                         float* dlogits, int B, int H, int W, TermCoef k) {
+    __shared__ float sp[TILE + 4][TILE + 4], st[TILE + 4][TILE + 4];
+    __shared__ float su[TILE + 2][TILE + 2], sv[TILE + 2][TILE + 2];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    const float* L = logits + (int64_t)b * H * W;
+    const float* Tt = targets + (int64_t)b * H * W;
+    const int tid = threadIdx.x;
+    const float inv_all = 1.f / ((float)B * (float)H * (float)W);
+    const float* s = sums + b * NS;
+    const bool do_edge = k.w_edge != 0.f;
+    if (do_edge) {
+        for (int i = tid; i < (TILE + 4) * (TILE + 4); i += 256) {
+            const int ly = i / (TILE + 4), lx = i % (TILE + 4);
+            const int y = y0 + ly - 2, x = x0 + lx - 2;
+            const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            sp[ly][lx] = in ? sigmoidf_(L[(int64_t)y * W + x]) : 0.f;
+            st[ly][lx] = in ? Tt[(int64_t)y * W + x] : 0.f;
+        }
+        __syncthreads();
+        for (int i = tid; i < (TILE + 2) * (TILE + 2); i += 256) {
+            const int ly = i / (TILE + 2), lx = i % (TILE + 2);
+            const int y = y0 + ly - 1, x = x0 + lx - 1;
+            float u = 0.f, v = 0.f;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                SOBEL(sp, gxp, gyp)
+                SOBEL(st, gxt, gyt)
+                const float mp = sqrtf(gxp * gxp + gyp * gyp + 1e-8f);
+                const float mt = sqrtf(gxt * gxt + gyt * gyt + 1e-8f);
+                const float d = mp - mt;
+                const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                u = sg * gxp / mp;
+                v = sg * gyp / mp;
+            }
+            su[ly][lx] = u;
+            sv[ly][lx] = v;
+        }
+        __syncthreads();
+    }
+    const int ly = tid / TILE, lx = tid % TILE;
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= H || x >= W) return;
+    const float l = L[(int64_t)y * W + x], t = Tt[(int64_t)y * W + x];
+    const float p = sigmoidf_(l);
+    float g = k.w_bce * inv_all * (p - t);
+    if (k.w_ratio != 0.f) {
+        const float Nn = k.nu * s[2] + k.s_n, D = k.d_tp * s[2] + k.d_p * s[1] + k.d_t * s[0] + k.s_d;
+        g += -(k.w_ratio / (float)B) * (k.nu * t * D - Nn * (k.d_tp * t + k.d_p)) / (D * D) * p * (1.f - p);
+    }
+    if (do_edge) {
+        const float ax = (su[ly + 2][lx + 2] - su[ly + 2][lx]) + 2.f * (su[ly + 1][lx + 2] - su[ly + 1][lx]) +
+                         (su[ly][lx + 2] - su[ly][lx]);
+        const float ay = (sv[ly + 2][lx + 2] + 2.f * sv[ly + 2][lx + 1] + sv[ly + 2][lx]) -
+                         (sv[ly][lx + 2] + 2.f * sv[ly][lx + 1] + sv[ly][lx]);
+        g += k.w_edge * inv_all * (ax + ay) * p * (1.f - p);
+    }
+    dlogits[(int64_t)b * H * W + (int64_t)y * W + x] = g;
+}
+
 __global__ void seg_metrics_kernel(const float* sums, float* out, int B) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float d = 0.f, i = 0.f;
@@ -233,6 +319,23 @@ extern "C" int aau_criterion(const float* logits, const float* targets, float* s
         hipLaunchKernelGGL(crit_grad_kernel, grid, dim3(256), 0, s, logits, targets, sums, dlogits, B, H, W, finetune,
                            neg_bce_w, edge_w, loss_scale);
     return check_launch("aau_criterion");
+}
+
+extern "C" int aau_loss_terms(const float* logits, const float* targets, float* sums, float* loss_out, float* dlogits,
+                              int B, int H, int W, const float* coef9, void* stream) {
+    AAU_REQUIRE(logits && targets && sums && loss_out && coef9 && B > 0 && B <= 4096 && H > 0 && W > 0,
+                "aau_loss_terms: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(3, 0, s);
+    const TermCoef k{coef9[0], coef9[1], coef9[2], coef9[3], coef9[4], coef9[5], coef9[6], coef9[7], coef9[8]};
+    zero_f32(sums, (int64_t)NREP * B * NS, s);
+    dim3 grid((W + TILE - 1) / TILE, (H + TILE - 1) / TILE, B);
+    hipLaunchKernelGGL(crit_reduce_kernel, grid, dim3(256), 0, s, logits, targets, sums, H, W, 0.f, k.w_edge != 0.f ? 1 : 0);
+    hipLaunchKernelGGL(crit_fold_kernel, dim3((B * NS + 255) / 256), dim3(256), 0, s, sums, B);
+    hipLaunchKernelGGL(terms_loss_kernel, dim3(1), dim3(64), 0, s, sums, loss_out, B, (float)H * (float)W, k);
+    if (dlogits)
+        hipLaunchKernelGGL(terms_grad_kernel, grid, dim3(256), 0, s, logits, targets, sums, dlogits, B, H, W, k);
+    return check_launch("aau_loss_terms");
 }
 
 extern "C" int aau_seg_metrics(const float* logits, const float* targets, float* sums, float* metrics_out, int B,

@@ -52,6 +52,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* m, float* v
     }
 }
 
+// Same update with the hyper-parameters in DEVICE memory (a replayed hipGraph then follows the LR schedule) and one
+// (lr, weight_decay) pair per parameter group: hyp = [G][2] fp32, group_of_block = group id of every 64-element block of
+// the flat buffers (parameters are 64-element aligned), or null for one group.  test_ablation.py:576-586 trains the
+// attention parameters at twice the backbone's rate.
+__global__ __launch_bounds__(256) void adamw_groups_kernel(float* p, float* m, float* v, const float* g, int64_t n,
+                                                           const float* norm_ws, const int64_t* step_dev,
+                                                           const float* hyp, const unsigned char* group_of_block,
+                                                           float b1, float b2, float eps, float max_norm,
+                                                           float inv_scale) {
+    const float sq = norm_ws[0];
+    if (!(sq < INFINITY)) return;
+    const float total = sqrtf(sq);
+    float coef = max_norm > 0.f ? max_norm / (total + 1e-6f) : 1.f;
+    coef = fminf(coef, 1.f) * inv_scale;
+    const double t = (double)(step_dev[0] + 1);
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float sqrt_bc2 = (float)sqrt(1.0 - pow((double)b2, t));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int grp = group_of_block ? group_of_block[i >> 6] : 0;
+        const float lr = hyp[2 * grp], wd = hyp[2 * grp + 1];
+        const float step_size = lr / bc1, decay = 1.f - lr * wd;
+        const float gi = g[i] * coef;
+        const float pi = p[i] * decay;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
 __global__ void step_inc_kernel(const float* norm_ws, int64_t* step_dev) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && norm_ws[0] < INFINITY) step_dev[0] += 1;
 }
@@ -128,6 +160,22 @@ extern "C" int aau_adamw_step(float* p, float* m, float* v, const float* g, int6
                        beta1, beta2, eps, weight_decay, max_norm, inv_scale);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, norm_ws, step_dev);
     return check_launch("aau_adamw_step");
+}
+
+extern "C" int aau_adamw_step_dev(float* p, float* m, float* v, const float* g, int64_t n, const float* norm_ws,
+                                  int64_t* step_dev, const float* hyp, const unsigned char* group_of_block, int n_groups,
+                                  float beta1, float beta2, float eps, float max_norm, float inv_scale, void* stream) {
+    AAU_REQUIRE(p && m && v && g && norm_ws && step_dev && hyp && n > 0, "aau_adamw_step_dev: bad args");
+    AAU_REQUIRE(n_groups >= 1 && n_groups <= 256 && (n_groups == 1 || group_of_block),
+                "aau_adamw_step_dev: %d groups need a block->group table", n_groups);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(3, 0, s);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, m, v, g, n, norm_ws, step_dev, hyp,
+                       n_groups > 1 ? group_of_block : nullptr, beta1, beta2, eps, max_norm, inv_scale);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, norm_ws, step_dev);
+    return check_launch("aau_adamw_step_dev");
 }
 
 extern "C" int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_pack_entry* table_dev,

@@ -390,6 +390,11 @@ static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipS
     }
     a.ws = ws;
     a.rev = next_traversal();
+    {
+        char tag[AAU_PROF_TAG_LEN];
+        snprintf(tag, sizeof(tag), "wgrad<%d,%d>%s", TQ, TC, T > 1 ? (d.dil > 1 ? " dilated" : " taps") : "");
+        prof_tag(tag);
+    }
     hipLaunchKernelGGL((wgrad_kernel<TQ, TC>), dim3((unsigned)grid), dim3(256), 0, s, a);
     if (!ws) return check_launch("aau_conv_wgrad");
     WRedArgs r;
@@ -426,6 +431,7 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
         if (need) return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream);
         const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
         ProfScope prof(1, flops, (hipStream_t)stream);
+        prof_tag("wgrad3x3<3,8>", 2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout) + 4.0 * d->Cout * 9.0 * d->Cin);
         return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream);
     }
     const bool q2 = d->Cout > 48, c2 = d->Cin > 48;
@@ -437,6 +443,7 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
     }
     const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
     ProfScope prof(1, flops, (hipStream_t)stream);
+    prof_tag(nullptr, 2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout) + 4.0 * d->Cout * (double)(d->KH * d->KW) * d->Cin);
     if (q2 && c2) return launch<2, 2>(a, ws, ws_bytes, nullptr, (hipStream_t)stream);
     if (q2) return launch<2, 1>(a, ws, ws_bytes, nullptr, (hipStream_t)stream);
     if (c2) return launch<1, 2>(a, ws, ws_bytes, nullptr, (hipStream_t)stream);

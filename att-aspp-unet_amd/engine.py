@@ -40,6 +40,14 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+def _short(conv_name: str) -> str:
+    """'u4.conv.0.block.0' -> 'u4.conv.0', 'bridge.blocks.1.0' -> 'bridge.blocks.1' (layer labels of the profiler)."""
+    for suf in (".block.0", ".0"):
+        if conv_name.endswith(suf):
+            return conv_name[:-len(suf)]
+    return conv_name
+
+
 class _Rec:
     """Recorded launch list.  Tensors are turned into raw pointers at record time and kept alive.
 
@@ -55,6 +63,8 @@ class _Rec:
         self.uses_side = False
         self.wg_ops = []        # (op index, workspace bytes) of the weight-gradient launches
 
+    label = ""   # caller-side name attached to the ops recorded from now on (layer name; shown by the profiler)
+
     def add(self, name, *args, side=False):
         f = _abi.fn(name)
         conv = []
@@ -67,7 +77,7 @@ class _Rec:
                 conv.append(C.byref(a))
             else:
                 conv.append(a)
-        self.ops.append((f, tuple(conv), name, 1 if side else 0))
+        self.ops.append((f, tuple(conv), name, 1 if side else 0, self.label))
         self.uses_side |= side
 
     def add_wgrad(self, desc, src, dz, dw, side=False):
@@ -83,17 +93,17 @@ class _Rec:
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         self.keep.append(ws)
         for i, _ in self.wg_ops:
-            f, a, name, sid = self.ops[i]
-            self.ops[i] = (f, a[:4] + (ws.data_ptr(), nbytes), name, sid)
+            f, a, name, sid, lab = self.ops[i]
+            self.ops[i] = (f, a[:4] + (ws.data_ptr(), nbytes), name, sid, lab)
 
     def callback(self, fn: Callable[[], None]):
-        self.ops.append((None, fn, "callback", 0))
+        self.ops.append((None, fn, "callback", 0, ""))
 
     def fork(self):
-        self.ops.append((None, None, "fork", 0))
+        self.ops.append((None, None, "fork", 0, ""))
 
     def join(self):
-        self.ops.append((None, None, "join", 0))
+        self.ops.append((None, None, "join", 0, ""))
 
     def run(self, stream: int):
         # alternate the traversal direction of the streaming kernels (aau_traverse): a consumer that starts where
@@ -137,7 +147,9 @@ class _Rec:
             side_t = self.side
             side = side_t.cuda_stream
             main_t = torch.cuda.current_stream()
-        for f, a, name, sid in (self.ops if ops_ is None else ops_):
+        prof = _abi.PROF_ON
+        setlab = _abi.fn("aau_prof_label") if prof else None
+        for f, a, name, sid, lab in (self.ops if ops_ is None else ops_):
             if f is None:
                 if name == "fork":
                     if side_t is not None:
@@ -148,6 +160,8 @@ class _Rec:
                 else:
                     a()
                 continue
+            if prof:
+                setlab(f"{lab}:{name[4:]}".encode())
             rc = f(*a, side if sid else stream)
             if rc != 0:
                 _abi.check(rc, name)
@@ -315,6 +329,7 @@ class Plan:
         self.eng, self.B, self.H, self.W, self.train = eng, B, H, W, train
         self.dev = eng.store.device
         self.fwd, self.bwd = _Rec(), _Rec()
+        self.fwd_gen, self.bwd_gen = 0, -1   # training forwards run / generation whose backward has run (model._NetFn)
         # dropout seed in device memory, advanced on the stream once per training forward (graph-capturable)
         self.drop_seed = torch.tensor([eng.next_seed() >> 1], dtype=torch.int64, device=eng.store.device)
         self.drop_p = float(eng.model.bridge.project[3].p) if train else 0.0
@@ -354,6 +369,7 @@ class Plan:
         alone, so BN + ReLU + out_conv run as one pass and neither the activation nor its gradient is stored."""
         st = self.eng.store
         cv, bn = st.convs[cname], st.bns[bname]
+        self.fwd.label = _short(cname)
         M = N * H * W
         pad = cv.dil * (cv.k // 2)
         w = self.bnbuf(bn.C)
@@ -395,6 +411,7 @@ class Plan:
         cv, bn, w = r["cv"], r["bn"], r["w"]
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
+        b.label = _short(cv.name)
         dp_ = self.drop_p if r["drop"] else 0.0
         fuse1 = cv.kind == "first" and dpool is None and dp_ == 0.0 and not self.eng.no_fuse_conv1
         dz = None if fuse1 else self.new(M, cv.O)
@@ -462,6 +479,7 @@ class Plan:
         Cs = [c, 2 * c, 4 * c, 8 * c, 16 * c]
 
         # weights: one table-driven repack per step
+        f.label = "pack"
         f.add("aau_pack_weights", st.flat, st.packed, st.pack_table, st.pack_n, st.pack_blocks)
 
         # ---------------- encoder ----------------
@@ -472,6 +490,7 @@ class Plan:
         enc = []  # (rec0, rec1) per level
         # d1.0: direct kernel on the fp32 frame
         cv0, bn0 = st.convs["d1.0.block.0"], st.bns["d1.0.block.1"]
+        f.label = "d1.0"
         w0 = self.bnbuf(c)
         y10 = self.new(Ms[0], c)
         r10 = dict(cv=cv0, bn=bn0, w=w0, N=B, H=H, W=W, M=Ms[0], src=self.x, sp=1, drop=False, bcast_hw=0)
@@ -516,6 +535,7 @@ class Plan:
                            cat5[:, i * Cb:], ncat) for i in range(nbr)]
         pooled = self.new(B, Cs[3])
         gap_ws = self.new(B, max(Cs[3], Cb), dtype=F32)
+        f.label = "bridge.pool"
         f.add("aau_gap_fwd", p4, Cs[3], pooled, gap_ws, B, h5 * w5, Cs[3])
         rpool = self.cbr_fwd("bridge.pool.1", "bridge.pool.2", pooled, Cs[3], B, 1, 1, cat5[:, nbr * Cb:], ncat,
                              bcast_hw=h5 * w5)
@@ -533,6 +553,7 @@ class Plan:
             up = st.convs[f"{name}.up"]
             cat = cat1 if lv == 0 else self.new(Mo, 2 * Co)
             dup = ops.conv_desc(B, hi, wi, g_c, g_c, hi, wi, 4 * Co, 2 * Co, Cpad=up.cpad_f, shuffle2x2=1)
+            f.label = f"{name}.up"
             f.add("aau_conv_igemm", dup, g_in, up.pk_f, cat[:, Co:], up.bias, None, None, None)
             gate = None
             if lv > 0:
@@ -542,6 +563,7 @@ class Plan:
                 psi = st.convs[f"{name}.att.psi.0"]
                 wgb, wxb, w1 = self.bnbuf(Fi), self.bnbuf(Fi), self.bnbuf(1)
                 zg, zx = self.new(Mo, Fi), self.new(Mo, Fi)
+                f.label = f"{name}.att"
                 psi_pre = self.new(Mo, dtype=F32)
                 alpha = self.new(Mo, dtype=F32)
                 dg = ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi, Cpad=wg.cpad_f)
@@ -576,6 +598,7 @@ class Plan:
             g_in, g_c = yb, Co
         oc = st.convs["out_conv"]
         fused_head = g_in is None
+        f.label = "out_conv"
         if not fused_head:
             f.add("aau_outconv_fwd", g_in, c, oc.w, oc.bias, self.logits, Ms[0], c)
         if not tr:
@@ -586,6 +609,7 @@ class Plan:
         mark = self._mark
         rep_ws = self.rep_ws = self.new(STAT_REPLICAS * (max(Cs) + 8), dtype=F32)   # replica scratch of the column reductions
         dy = None
+        b.label = "out_conv"
         if not fused_head:
             dy = self.new(Ms[0], c)
             b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, rep_ws, Ms[0], c)
@@ -603,6 +627,7 @@ class Plan:
                 dcat1 = dcat
             cat, gt, up = blk["cat"], blk["gate"], blk["up"]
             if gt is not None:
+                b.label = f"{blk['name']}.att"
                 Fi = gt["Fi"]
                 w1, wgb, wxb = gt["w1"], gt["wgb"], gt["wxb"]
                 dq = self.new(Mo, dtype=F32)
@@ -631,6 +656,7 @@ class Plan:
                                                       accumulate=1), dzx, wx.pk_d, dskip[lv], None, None, None, None)
             # ConvTranspose2d backward: bias, weight, input
             gsrc, gc = blk["g_in"], blk["g_c"]
+            b.label = f"{blk['name']}.up"
             if sA is None:
                 b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, rep_ws, Mo, Co)
             else:
@@ -654,11 +680,13 @@ class Plan:
         for i, r in enumerate(br):
             self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0)
         dpb = self.new(B, Cb)
+        b.label = "bridge.pool"
         b.add("aau_spatial_sum", dcat5[:, nbr * Cb:], ncat, dpb, gap_ws, B, h5 * w5, Cb)
         dpooled = self.new(B, Cs[3])
         rpool_b = dict(rpool)
         rpool_b["bcast_hw"] = 0
         self.cbr_bwd(rpool_b, dpb, Cb, din=dpooled, dinp=Cs[3])
+        b.label = "bridge.pool"
         b.add("aau_gap_bwd", dpooled, dp4, Cs[3], B, h5 * w5, Cs[3])
         mark("bridge")
         # encoder
@@ -693,6 +721,7 @@ class Plan:
         if x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
         if self.train:
+            self.fwd_gen += 1
             self.stats_arena.buf.zero_()
             self.drop_seed.add_(0x9E3779B97F4A7C15 - (1 << 64))   # odd increment mod 2^64: a new mask every step
         self.fwd.run(stream)
@@ -719,7 +748,7 @@ class Engine:
         self.model = model
         self.store: ParamStore | None = None
         self.plans: dict = {}
-        self._seed = 0x5EED
+        self._seed = None       # dropout seed chain: drawn from torch's RNG (and the DP rank) on first use
         self.bucket_cb = None   # set by the data-parallel wrapper: name -> callable
         import os
         self.overlap_wgrad = os.environ.get("AAU_OVERLAP_WGRAD", "0") == "1"   # measured null on MI355X (A/B, same device)
@@ -734,6 +763,14 @@ class Engine:
         self.no_fuse_bnred = os.environ.get("AAU_FUSE_BNRED", "0") != "1"
 
     def next_seed(self) -> int:
+        """Seeds of the Dropout masks follow ``torch.manual_seed`` (pipeline:33-52 ``set_seed``): the chain starts from
+        torch's seed mixed with the data-parallel rank, so two seeds -- or two ranks -- give different
+        mask streams and the same seed reproduces them (``initial_seed`` is read, the generator state is not consumed)."""
+        if self._seed is None:
+            import torch.distributed as dist
+            base = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._seed = (base ^ (0x9E3779B97F4A7C15 * (rank + 1))) & 0xFFFFFFFFFFFFFFFF
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._seed
 

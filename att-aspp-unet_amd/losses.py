@@ -4,9 +4,9 @@ computed by the fused HIP criterion kernels (csrc/loss.hip).
 ``build_criterion(args, base, edge)`` keeps the reference signature and returns
 ``crit(logits, targets) -> scalar``; forward value and d/dlogits come from two launches
 with no host synchronisation (the reference's ``nonzero``/index selection of positive
-samples is restated with a per-sample mask, see csrc/loss.hip).  The standalone loss
-classes exist for API parity; they evaluate forward values from the same per-sample
-sums and carry no autograd graph.
+samples is restated with a per-sample mask, see csrc/loss.hip).  The loss classes used on
+their own (``DiceLoss`` / ``TverskyLoss`` / ``ComboLoss`` / ``EdgeLoss``) are autograd nodes
+over ``aau_loss_terms`` (same per-sample sums, every sample counted).
 """
 from __future__ import annotations
 
@@ -52,46 +52,67 @@ class _CritFn(torch.autograd.Function):
         return dl * g, None, None, None, None
 
 
+class _TermsFn(torch.autograd.Function):
+    """One of the loss classes on its own: value and d/dlogits from aau_loss_terms (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, l, t, coef9):
+        B, _, H, W = l.shape
+        sums = torch.empty(32, B, 8, device=l.device)
+        out = torch.empty(4, device=l.device)
+        dl = torch.empty_like(l) if ctx.needs_input_grad[0] else None
+        ops.loss_terms(l, t, sums, out, dl, B, H, W, coef9)
+        if dl is not None:
+            ctx.save_for_backward(dl)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None
+
+
+def _terms(l, t, coef9):
+    l, t = _check(l, t)
+    return _TermsFn.apply(l, t, tuple(coef9))
+
+
 class DiceLoss(nn.Module):
-    """pipeline:173-178 (forward value only)."""
+    """pipeline:173-178: mean over samples of 1 - (2*sum(p*t) + s)/(sum p + sum t + s); differentiable."""
 
     def __init__(self, smooth=1.):
         super().__init__()
         self.s = smooth
 
     def forward(self, l, t):
-        s = sample_sums(l, t, edge=False)
-        return (1 - (2 * s[:, 2] + self.s) / (s[:, 1] + s[:, 0] + self.s)).mean()
+        return _terms(l, t, (1., 2., self.s, 0., 1., 1., self.s, 0., 0.))
 
 
 class TverskyLoss(nn.Module):
-    """pipeline:180-185 (dead code in the reference; forward value only)."""
+    """pipeline:180-185 (dead code in the reference: LOSS_TYPE is "combo"); differentiable."""
 
     def __init__(self, a=0.7, b=0.3, s=1.):
         super().__init__()
         self.a, self.b, self.s = a, b, s
 
     def forward(self, l, t):
-        q = sample_sums(l, t, edge=False)
-        tp, fp, fn = q[:, 2], q[:, 1] - q[:, 2], q[:, 0] - q[:, 2]
-        return (1 - (tp + self.s) / (tp + self.a * fp + self.b * fn + self.s)).mean()
+        return _terms(l, t, (1., 1., self.s, 1. - self.a - self.b, self.a, self.b, self.s, 0., 0.))
 
 
 class ComboLoss(nn.Module):
-    """pipeline:187-189 (forward value only; gradients flow through build_criterion)."""
+    """pipeline:187-189: DiceLoss + BCEWithLogits (mean over all elements); differentiable."""
 
     def __init__(self):
         super().__init__()
         self.d = DiceLoss()
 
     def forward(self, l, t):
-        s = sample_sums(l, t, edge=False)
-        dice = (1 - (2 * s[:, 2] + 1.) / (s[:, 1] + s[:, 0] + 1.)).mean()
-        return dice + s[:, 3].sum() / (l.shape[0] * l.shape[2] * l.shape[3])
+        return _terms(l, t, (1., 2., self.d.s, 0., 1., 1., self.d.s, 1., 0.))
 
 
 class EdgeLoss(nn.Module):
-    """pipeline:196-216 (forward value only); keeps the kx / ky buffers of the reference."""
+    """pipeline:196-216: L1 distance of the Sobel magnitudes of sigmoid(logits) and targets; differentiable.
+    Keeps the kx / ky buffers of the reference (they are part of its state_dict)."""
 
     def __init__(self):
         super().__init__()
@@ -99,8 +120,7 @@ class EdgeLoss(nn.Module):
         self.register_buffer("ky", torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]]).view(1, 1, 3, 3))
 
     def forward(self, logits, targets):
-        s = sample_sums(logits, targets, edge=True)
-        return s[:, 4].sum() / (logits.shape[0] * logits.shape[2] * logits.shape[3])
+        return _terms(logits, targets, (0., 1., 1., 0., 1., 1., 1., 0., 1.))
 
 
 def build_criterion(args, base, edge):

@@ -113,17 +113,32 @@ class UpBlock(nn.Module):
 
 
 class _NetFn(torch.autograd.Function):
-    """One autograd node for the whole network: forward and backward are engine plans."""
+    """One autograd node for the whole network: forward and backward are engine plans.
+
+    A plan owns ONE set of activation buffers and the flat gradient buffer is rewritten by every backward, so the
+    node supports exactly the reference loop's pattern (pipeline:320-322): one training forward, then one backward.
+    A second training forward of the same shape before the backward, a second backward of the same forward
+    (``retain_graph``) and gradient accumulation over several backward calls are NOT supported and raise instead of
+    returning gradients of the wrong activations."""
 
     @staticmethod
     def forward(ctx, x, trigger, plan):
         ctx.plan = plan
         out = plan.run_forward(x)
+        ctx.gen = plan.fwd_gen
         return out.clone()
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.plan.run_backward(dlogits.contiguous())
+        plan = ctx.plan
+        if ctx.gen != plan.fwd_gen:
+            raise _abi.AauError("backward of a forward whose activations were overwritten by a later training forward "
+                                "of the same shape (one plan = one set of activation buffers)")
+        if plan.bwd_gen == ctx.gen:
+            raise _abi.AauError("second backward through the same forward (retain_graph / gradient accumulation are "
+                                "not supported: every backward rewrites the flat gradient buffer)")
+        plan.bwd_gen = ctx.gen
+        plan.run_backward(dlogits.contiguous())
         return None, None, None
 
 

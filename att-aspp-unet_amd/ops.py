@@ -238,9 +238,32 @@ def criterion(logits, targets, sums, loss_out, dlogits, B, H, W, finetune=False,
                               1 if finetune else 0, neg_bce_w, edge_w, loss_scale, _stream()), "aau_criterion")
 
 
+def loss_terms(logits, targets, sums, loss_out, dlogits, B, H, W, coef9):
+    """coef9 = (w_ratio, nu, s_n, d_tp, d_p, d_t, s_d, w_bce, w_edge); see include/aau.h."""
+    arr = (C.c_float * 9)(*[float(v) for v in coef9])
+    check(fn("aau_loss_terms")(_p(logits), _p(targets), _p(sums), _p(loss_out), _p(dlogits), B, H, W, arr, _stream()),
+          "aau_loss_terms")
+
+
 def seg_metrics(logits, targets, sums, out, B, H, W, thr=0.5):
     check(fn("aau_seg_metrics")(_p(logits), _p(targets), _p(sums), _p(out), B, H, W, thr, _stream()),
           "aau_seg_metrics")
+
+
+def seg_counts(a, b):
+    """-> (|a > 0|, |b > 0|, |both|) as Python ints; a, b device tensors of equal shape (evalseg:41-49)."""
+    def prep(t):
+        if t.dtype == torch.bool:
+            t = t.view(torch.uint8)
+        elif t.dtype not in (torch.uint8, torch.float32):
+            t = (t > 0).to(torch.uint8)
+        return t.contiguous()
+    a, b = prep(a), prep(b)
+    out = torch.empty(3, dtype=torch.int64, device=a.device)
+    check(fn("aau_seg_counts")(_p(a), int(a.dtype == torch.float32), _p(b), int(b.dtype == torch.float32), a.numel(),
+                               _p(out), _stream()), "aau_seg_counts")
+    na, nb, ni = out.tolist()
+    return int(na), int(nb), int(ni)
 
 
 def grad_sqnorm(grad, n, inv_scale, ws):
@@ -251,6 +274,14 @@ def adamw_step(p, m, v, g, n, norm_ws, step_dev, lr, beta1=0.9, beta2=0.999, eps
                max_norm=1.0, inv_scale=1.0):
     check(fn("aau_adamw_step")(_p(p), _p(m), _p(v), _p(g), n, _p(norm_ws), _p(step_dev), lr, beta1, beta2, eps,
                                weight_decay, max_norm, inv_scale, _stream()), "aau_adamw_step")
+
+
+def adamw_step_dev(p, m, v, g, n, norm_ws, step_dev, hyp, group_of_block, n_groups, beta1=0.9, beta2=0.999, eps=1e-8,
+                   max_norm=1.0, inv_scale=1.0):
+    """AdamW with (lr, weight_decay) per parameter group read from the device tensor ``hyp`` [n_groups, 2]."""
+    check(fn("aau_adamw_step_dev")(_p(p), _p(m), _p(v), _p(g), n, _p(norm_ws), _p(step_dev), _p(hyp),
+                                   _p(group_of_block), n_groups, beta1, beta2, eps, max_norm, inv_scale, _stream()),
+          "aau_adamw_step_dev")
 
 
 def f32_to_bf16(src, dst, n):

@@ -18,7 +18,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import ops, synth
+from . import _abi, ops, synth
 from .losses import ComboLoss, DiceLoss, EdgeLoss, build_criterion, seg_metrics
 from .model import AttentionASPPUNet
 from .optim import FusedAdamW
@@ -148,20 +148,31 @@ class SyntheticLoader:
 
 def train(args, train_loader=None, val_loader=None):
     """pipeline:244-333.  Same optimiser / schedule / clipping / early stopping / best-checkpoint logic;
-    bf16 activations with fp32 master weights instead of fp16 autocast + GradScaler."""
+    bf16 activations with fp32 master weights instead of fp16 autocast + GradScaler.
+
+    Data parallel: when ``torch.distributed`` is initialised with more than one rank (one process per GPU, launched by
+    ``python -m torch.distributed.run``), the model is wrapped in ``parallel.DataParallel``: every rank trains on its
+    own shard (the synthetic loader is seeded per rank; a caller-supplied loader must shard itself), gradients are
+    all-reduced in buckets under the backward pass, and every rank applies the same update.  Validation runs on every
+    rank over the same set (identical decisions everywhere); rank 0 alone prints and writes checkpoints."""
+    import torch.distributed as dist
+    from .parallel import DataParallel
     set_seed(args.seed)
-    device = torch.device("cuda")
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    device = torch.device("cuda", torch.cuda.current_device())
     if train_loader is None:
         n = int(getattr(args, "synthetic_batches", 0) or 0)
         if n <= 0:
             raise RuntimeError("no dataset reader on this machine (cv2/albumentations absent): pass loaders or --synthetic_batches N")
         size = int(getattr(args, "img_size", IMG_SIZE))
-        train_loader = SyntheticLoader(n, args.batch_size, size, args.seed, device)
+        train_loader = SyntheticLoader(n, args.batch_size, size, args.seed + 7919 * rank, device)
         val_loader = SyntheticLoader(max(1, n // 10), args.batch_size, size, args.seed + 100000, device, neg_frac=0.0)
     model = AttentionASPPUNet(base_c=args.base_c).to(device)
     if args.stage == "finetune":
         load_state_dict_compat(model, args.pretrained)
         print(f"loaded pretrained {args.pretrained}")
+    dp = DataParallel(model) if world > 1 else None
     opt = FusedAdamW(model, lr=args.lr, weight_decay=WEIGHT_DECAY, max_grad_norm=GRAD_CLIP)
     tot_ep = args.epochs
     crit = build_criterion(args, ComboLoss(), EdgeLoss())
@@ -178,21 +189,39 @@ def train(args, train_loader=None, val_loader=None):
             opt.zero_grad(set_to_none=True)
             loss = crit(model(x), y)
             loss.backward()
-            opt.step()
+            if dp is not None:
+                dp.finish()                      # the bucket all-reduces were issued from inside the backward pass
+                opt.step(inv_scale=dp.inv_scale)
+            else:
+                opt.step()
             run += loss.detach()
         d, i = evaluate(model, val_loader, device)
         history.append((float(run) / max(len(train_loader), 1), d, i))
-        print(f"Epoch {ep}/{tot_ep} loss {history[-1][0]:.4f} | Dice {d:.4f} | IoU {i:.4f}")
+        if rank == 0:
+            print(f"Epoch {ep}/{tot_ep} loss {history[-1][0]:.4f} | Dice {d:.4f} | IoU {i:.4f}")
         if d > best:
             best, noimp = d, 0
-            torch.save({k: v.contiguous() for k, v in model.state_dict().items()}, best_p)
-            print(f"best saved -> {best_p}")
+            if rank == 0:
+                torch.save({k: v.contiguous() for k, v in model.state_dict().items()}, best_p)
+                print(f"best saved -> {best_p}")
         else:
             noimp += 1
             if noimp >= EARLY_STOP_PATIENCE:
-                print("Early stop")
+                if rank == 0:
+                    print("Early stop")
                 break
     return model, history
+
+
+def _mask_f32(y, B, H, W, device):
+    """The fused criterion reads ``y`` as B*H*W fp32 values: anything else (uint8 / bool / bf16 masks, a strided view, a
+    host tensor) is converted here, and a wrong shape raises, instead of being misread by the kernel."""
+    if not isinstance(y, torch.Tensor) or y.numel() != B * H * W or y.dim() != 4 or tuple(y.shape) != (B, 1, H, W):
+        raise _abi.AauError(f"targets must be a [{B},1,{H},{W}] tensor, got "
+                            f"{tuple(y.shape) if isinstance(y, torch.Tensor) else type(y)}")
+    if y.device != device or y.dtype != torch.float32 or not y.is_contiguous():
+        y = y.to(device=device, dtype=torch.float32).contiguous()
+    return y
 
 
 class TrainStep:
@@ -212,6 +241,7 @@ class TrainStep:
         assert m.training, "TrainStep needs model.train()"
         plan = m._plan_for(x)
         B, _, H, W = x.shape
+        y = _mask_f32(y, B, H, W, x.device)
         if self.sums is None or self.sums.shape[1] != B:
             self.sums = torch.zeros(32, B, 8, device=x.device)
             self.loss = torch.zeros(4, device=x.device)
@@ -231,14 +261,18 @@ class GraphedTrainStep:
     launch list is cut at the gradient-bucket marks: one graph per segment, and the RCCL all-reduce of a bucket is
     issued (eagerly, on its own stream) between two graph launches -- the collectives are not captured, the ~290 kernel
     launches of the step are.  (Measured on one MI355X with world size 1: the segmented form is 1 % slower than the
-    eager launch list, which itself is within 1 % of the single graph, so bench.py keeps N > 1 eager.)  Inputs are copied into static buffers, so any ``(x, y)`` of the captured shape works.
-    The learning rate is a launch argument: re-create the object when the scheduler changes it (once per epoch)."""
+    eager launch list, which itself is within 1 % of the single graph, so bench.py keeps N > 1 eager.)  Inputs are copied
+    into static buffers (the mask is converted to fp32 on the way), so any ``(x, y)`` of the captured shape works.
+    Nothing that changes from step to step is baked into the graph: step count and dropout seed advance in device
+    memory, and the learning rate / weight decay are read from the optimiser's device table, refreshed before each
+    replay, so an LR scheduler keeps working (pipeline:303-306,325)."""
 
     def __init__(self, step: "TrainStep", x, y, warmup: int = 2):
         self.step = step
         m, dp = step.model, step.dp
         assert m.training
-        self.x, self.y = x.clone(), y.clone()
+        B, _, H, W = x.shape
+        self.x, self.y = x.float().contiguous().clone(), _mask_f32(y, B, H, W, x.device).clone()
         for _ in range(max(warmup, 1 if step.sums is None else 0)):   # plan, optimiser state, allocator pools
             step(self.x, self.y)
         torch.cuda.synchronize()
@@ -284,10 +318,14 @@ class GraphedTrainStep:
         return g
 
     def __call__(self, x, y):
+        if tuple(x.shape) != tuple(self.x.shape) or tuple(y.shape) != tuple(self.y.shape):
+            raise _abi.AauError(f"GraphedTrainStep was captured for {tuple(self.x.shape)} / {tuple(self.y.shape)}, "
+                                f"got {tuple(x.shape)} / {tuple(y.shape)}")
         if x.data_ptr() != self.x.data_ptr():
-            self.x.copy_(x, non_blocking=True)
+            self.x.copy_(x, non_blocking=True)        # copy_ converts dtype / layout / device
         if y.data_ptr() != self.y.data_ptr():
             self.y.copy_(y, non_blocking=True)
+        self.step.opt.refresh_hyper()                 # LR schedule: a 16-byte upload when it changed, outside the graph
         for g, cb in self.parts:
             if g is not None:
                 g.replay()

@@ -6,10 +6,13 @@ batch 8 per GPU, bf16 activations / fp32 master weights, synthetic ultrasound ph
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
-  roofline     dominant kernel family = the MFMA implicit-GEMM convolutions (forward, data- and
-               weight-gradient launches): algorithmic conv FLOPs of the step (680.05 GFLOP/image,
-               BASELINE.md section 2) / summed kernel time of those launches, measured with HIP
-               events around every launch on the launch stream in a second pass of the same steps.
+  roofline     the DOMINANT KERNEL of the step (the kernel variant with the largest summed time among
+               the MFMA convolution launches; today conv3x3g<96>): algorithmic FLOPs of its launches /
+               their summed duration, measured live with HIP events around every launch on the launch
+               stream in a second (eager) pass of the same steps.  Beside it: `conv_family` (all conv
+               launches against the 680.05 GFLOP/image of BASELINE.md section 2), `by_kernel` (every conv
+               kernel variant) and `per_layer` (every conv launch of one step against
+               min(MFMA peak, arithmetic intensity x HBM bandwidth)).
   cpu_baseline the CPU oracle (oracle/ref_cpu.py, an ATen fp32 restatement of the reference step)
                timed on this host's cores on a bounded sample (rank 0, N=1 only).
 """
@@ -26,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 FWD_GFLOP_PER_IMAGE = {48: 226.76, 32: 100.84, 16: 25.25}
 PEAK_BF16_TFLOPS = 2500.0                                     # MI355X dense bf16 MFMA (guide, spec)
+PEAK_HBM_TBS = 8.0                                            # HBM3E (guide, spec; 6.3 TB/s measured copy rate)
 
 
 def train_gflop_per_image(base_c, size):
@@ -50,8 +54,9 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("AAU_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(base_c, size, seconds_budget=25.0):
-    """Time the CPU oracle's train step on a bounded sample of the same workload."""
+def cpu_baseline(base_c, size, batch=8, seconds_budget=40.0):
+    """Time the CPU oracle's train step on a bounded sample of the same workload: the metric's own batch (8), the
+    protocol of BASELINE.md section 3 (2 warm-up + 5 timed steps) when that fits the budget, fewer steps otherwise."""
     from argparse import Namespace
     from oracle import ref_cpu as O
     from att_aspp_unet_amd import synth
@@ -62,20 +67,120 @@ def cpu_baseline(base_c, size, seconds_budget=25.0):
     net.train()
     opt = O.make_optimizer(net, 3e-4)
     crit = O.build_criterion(Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05), O.ComboLoss(), O.EdgeLoss())
-    bs = 2
-    x, y = synth.make_frames(bs, size, seed=2025)
+    x, y = synth.make_frames(batch, size, seed=2025)
     t0 = time.perf_counter()
     O.train_step(net, opt, crit, x, y)                          # warm-up (also sizes the sample)
     warm = time.perf_counter() - t0
-    n = max(1, min(3, int(seconds_budget / max(warm, 1e-3)) - 1))
-    t0 = time.perf_counter()
-    for _ in range(n):
+    n = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    nwarm = 1
+    if n == 5 and warm * 7 <= seconds_budget * 1.6:
         O.train_step(net, opt, crit, x, y)
-    dt = (time.perf_counter() - t0) / n
-    return {"value": bs / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} timed + 1 warm-up fp32 train steps of the CPU oracle at batch {bs}, {size}x{size}, "
-                      f"base_c {base_c} (same step, smaller batch; BN needs >= 2)",
-            "sec_per_step": dt}
+        nwarm = 2
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        O.train_step(net, opt, crit, x, y)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": batch / med, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} timed + {nwarm} warm-up fp32 train steps (median) of the CPU oracle at batch {batch}, "
+                      f"{size}x{size}, base_c {base_c}: the metric's own step; BASELINE.md section 3 asks for 2 + 5, "
+                      f"the count is cut to a ~{int(seconds_budget)} s budget",
+            "sec_per_step": med, "sec_per_step_min": ts[0]}
+
+
+def roofline_from_records(recs, nprof, alg_flops, step_s, base_c, size, batch):
+    """Roofline object of the JSON line from the per-launch event records of `nprof` eager steps."""
+    per = len(recs) // nprof
+    conv = ("igemm", "wgrad")
+    fam = {}
+    for r in recs:
+        f = fam.setdefault(r["family"], {"ms": 0.0, "flops": 0.0, "launches": 0})
+        f["ms"] += r["ms"]; f["flops"] += r["flops"]; f["launches"] += 1
+    by = {}
+    for r in recs:
+        if r["family"] in conv:
+            k = by.setdefault(r["tag"] or "?", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["launches"] += 1
+    by_kernel = {}
+    for tag, k in sorted(by.items(), key=lambda kv: -kv[1]["ms"]):
+        tf = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        by_kernel[tag] = {"launches_per_step": k["launches"] / nprof, "gflop_per_step": k["flops"] / nprof / 1e9,
+                          "ms_per_step": k["ms"] / nprof, "tflops": tf, "frac_of_mfma_peak": tf / PEAK_BF16_TFLOPS,
+                          "alg_gbytes_per_step": k["bytes"] / nprof / 1e9}
+    dom_tag = next(iter(by_kernel))
+    dom = by_kernel[dom_tag]
+    # every conv launch of a step (mean over the profiled steps) against its own roofline
+    per_layer = []
+    if per * nprof == len(recs):
+        for i in range(per):
+            r0 = recs[i]
+            if r0["family"] not in conv or r0["flops"] <= 0:
+                continue
+            ms = sum(recs[s * per + i]["ms"] for s in range(nprof)) / nprof
+            tf = r0["flops"] / (ms * 1e-3) / 1e12
+            ai = r0["flops"] / r0["bytes"] if r0["bytes"] > 0 else float("inf")
+            roof = min(PEAK_BF16_TFLOPS, ai * PEAK_HBM_TBS)
+            per_layer.append([r0["label"], r0["tag"], round(r0["flops"] / 1e9, 2), round(r0["bytes"] / 1e6, 1),
+                              round(ms * 1e3, 1), round(tf, 1), round(roof, 1), round(tf / roof, 3)])
+    conv_ms = sum(fam.get(k, {"ms": 0.0})["ms"] for k in conv) / nprof
+    conv_launches = sum(fam.get(k, {"launches": 0})["launches"] for k in conv) // nprof
+    traffic = None
+    try:   # PMC passes of this very command (separate rocprofv3 runs, corrected as the guide prescribes): profiles/
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        if base_c == 48 and size == 512 and batch == 8:
+            k = pm["by_kernel"].get(dom_tag.split(" ")[0], None)
+            traffic = k["bytes_per_launch"] if k else None
+    except Exception:
+        pass
+    return {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "kernel": dom_tag, "dominant_kernel": dict(name=dom_tag, **dom),
+            "avg_launch_ms": dom["ms_per_step"] / max(dom["launches_per_step"], 1e-9),
+            "alg_bytes_per_launch": dom["alg_gbytes_per_step"] * 1e9 / max(dom["launches_per_step"], 1e-9),
+            "conv_family": {"launches_per_step": conv_launches, "ms_per_step": conv_ms,
+                            "algorithmic_flops_per_step": alg_flops,
+                            "tflops": alg_flops / (conv_ms * 1e-3) / 1e12,
+                            "frac": alg_flops / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
+            "ms_per_step_by_family": {k: v["ms"] / nprof for k, v in fam.items()},
+            "whole_step_frac": alg_flops / step_s / 1e12 / PEAK_BF16_TFLOPS,
+            "by_kernel": by_kernel,
+            "per_layer_columns": ["layer:call", "kernel", "GFLOP", "alg MB", "us", "TFLOP/s",
+                                  "roof = min(2500, AI x 8 TB/s)", "frac of roof"],
+            "per_layer": per_layer}
+
+
+def inference_numbers(dev):
+    """BASELINE configs 2 and 5 (not the metric): eval forward bs 4 and the 1024^2 sliding window, hipGraph replays."""
+    import att_aspp_unet_amd as A
+    from att_aspp_unet_amd import synth
+
+    def timeit(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    torch.manual_seed(2025)
+    m = A.AttentionASPPUNet(base_c=48).to(dev).eval()
+    x, _ = synth.make_frames(4, 512, seed=1)
+    x = x.to(dev)
+    gf = A.GraphedForward(m, (4, 1, 512, 512), device=dev)
+    t2 = timeit(lambda: gf(x))
+    m5 = A.AttentionASPPUNet(base_c=48, rates=(6, 12, 18, 24)).to(dev).eval()
+    big = torch.rand(1, 1, 1024, 1024, device=dev)
+    gf9 = A.GraphedForward(m5, (9, 1, 512, 512), device=dev)
+    t5 = timeit(lambda: A.predict_sliding_window(m5, big, 512, 256, forward=gf9), n=10)
+    return {"config2_fwd_bs4_512_bf16_hipgraph": {"ms": t2 * 1e3, "images_per_sec": 4 / t2,
+                                                  "conv_tflops": 4 * 226.76e9 / t2 / 1e12},
+            "config5_1024_sliding_window_9x512_rates_6_12_18_24_bf16_hipgraph": {"ms_per_frame": t5 * 1e3,
+                                                                                 "frames_per_sec": 1 / t5}}
 
 
 def main():
@@ -88,6 +193,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true", help="skip the inference side numbers (configs 2 and 5)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("AAU_BENCH_GRAPH", "1")),
                     help="replay the step as one hipGraph when possible")
     a = ap.parse_args()
@@ -164,36 +270,18 @@ def main():
 
     roof = None
     if not a.no_roofline and rank == 0:
-        # second pass of the same steps with every launch bracketed by HIP events on its stream
+        # second pass of the same steps (eager launch list) with every launch bracketed by HIP events on its stream
         nprof = min(a.steps, 5)
+        step(x, y)
+        torch.cuda.synchronize()
         _abi.prof_enable(True)
         for i in range(nprof):
             step(x, y)
         torch.cuda.synchronize()
         _abi.prof_enable(False)
-        prof = _abi.prof_collect()
-        conv_ms = (prof["igemm"]["ms"] + prof["wgrad"]["ms"]) / nprof
+        recs = _abi.prof_collect_launches()
         alg = train_gflop_per_image(a.base_c, a.size) * a.batch * 1e9
-        achieved = alg / (conv_ms * 1e-3) / 1e12
-        # HBM traffic of the conv launches: PMC passes (FETCH_SIZE, WRITE_SIZE in separate rocprofv3 runs of this
-        # very command, corrected as MI355X_MICROARCH.md prescribes) are stored under profiles/; bytes per launch
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pm = json.load(f)
-            if a.base_c == 48 and a.size == 512 and a.batch == 8:
-                traffic = pm["conv_kernels"]["bytes_per_launch"]
-        except Exception:
-            pass
-        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                "kernel": "igemm_kernel + wgrad_kernel (MFMA implicit-GEMM conv fwd/dgrad/wgrad)",
-                "launches_per_step": (prof["igemm"]["launches"] + prof["wgrad"]["launches"]) // nprof,
-                "avg_launch_ms": conv_ms / max(1, (prof["igemm"]["launches"] + prof["wgrad"]["launches"]) // nprof),
-                "algorithmic_flops_per_step": alg,
-                "ms_per_step_by_family": {k: v["ms"] / nprof for k, v in prof.items()},
-                "counted_flops_per_step": {k: v["flops"] / nprof for k, v in prof.items()},
-                "whole_step_frac": alg / (dt / a.steps) / 1e12 / PEAK_BF16_TFLOPS}
+        roof = roofline_from_records(recs, nprof, alg, dt / a.steps, a.base_c, a.size, a.batch)
     # The reference loop hands HOST batches to the device every step (pipeline:319: 2 x 8 MB at bs 8).  `value` is
     # measured with the inputs resident in HBM; this extra pass times the same steps with a pinned-host -> HBM copy of
     # the frames and the masks issued in front of each step (same stream: the worst case, no prefetch overlap).
@@ -212,9 +300,15 @@ def main():
     if world > 1:
         dist.barrier()
 
+    infer = None
+    if rank == 0 and world == 1 and not a.no_roofline and a.base_c == 48 and a.size == 512 and not a.no_infer:
+        try:
+            infer = inference_numbers(dev)
+        except Exception as e:   # reported, never fatal for the metric line
+            infer = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.base_c, a.size)
+        cpu = cpu_baseline(a.base_c, a.size, a.batch)
 
     if rank == 0:
         imgs = a.batch * world * a.steps
@@ -227,7 +321,8 @@ def main():
                                    f"base_c {a.base_c}, 1x{a.size}x{a.size}, batch {a.batch}/GPU, bf16 activations, "
                                    f"fp32 master weights" + (", RCCL grad all-reduce overlapped with backward" if world > 1 else ""),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
-                       "final_loss": loss_val, "images_per_sec_with_h2d_of_inputs": h2d},
+                       "final_loss": loss_val, "images_per_sec_with_h2d_of_inputs": h2d,
+                       "inference_not_the_metric": infer},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -55,6 +55,16 @@ int aau_prof_enable(int on);
 int aau_prof_collect(double ms[AAU_PROF_FAMILIES], int64_t launches[AAU_PROF_FAMILIES],
                      double flops[AAU_PROF_FAMILIES]);
 
+/* Per-launch form of the same records (clears them as well): up to cap launches in issue    */
+/* order with the kernel variant the launcher picked (tags: cap x AAU_PROF_TAG_LEN chars),    */
+/* event time [ms], algorithmic FLOPs and algorithmic HBM bytes (0 where not stated).         */
+/* tags[i] = "<caller label>|<kernel variant>"; the label is whatever aau_prof_label() set on   */
+/* the calling thread before the launch (the engine passes its layer names), consumed by it.  */
+#define AAU_PROF_TAG_LEN 96
+int aau_prof_label(const char* label);
+int aau_prof_collect_launches(int cap, int* n_out, char* tags, double* ms, double* flops,
+                              double* bytes, int* family);
+
 /* ---- implicit-GEMM convolution on MFMA --------------------------------------------- */
 /* One descriptor drives forward convolution (pipeline:63 Conv2d in ConvBNReLU, :71-78  */
 /* ASPP convs incl. dilation, :88-90 gate 1x1, :101 ConvTranspose2d as a 1x1 GEMM with a */
@@ -299,9 +309,23 @@ int aau_fold_replicas(const float* ws, int stride, float* out, int n, void* stre
 int aau_criterion(const float* logits, const float* targets, float* sums, float* loss_out,
                   float* dlogits, int B, int H, int W, int finetune, float neg_bce_w,
                   float edge_w, float loss_scale, void* stream);
+/* The loss classes on their own (pipeline:173-189 DiceLoss / TverskyLoss / ComboLoss, :196-216  */
+/* EdgeLoss; every sample counts):                                                               */
+/*   total = w_ratio*mean_b(1 - (nu*tp_b+s_n)/(d_tp*tp_b + d_p*sum p_b + d_t*sum t_b + s_d))      */
+/*         + w_bce*mean(bce) + w_edge*mean|grad p - grad t|                                       */
+/* coef9 (host) = {w_ratio, nu, s_n, d_tp, d_p, d_t, s_d, w_bce, w_edge}; loss_out fp32 [4] =     */
+/* total, ratio term, bce term, edge term; dlogits optional.                                     */
+int aau_loss_terms(const float* logits, const float* targets, float* sums, float* loss_out,
+                   float* dlogits, int B, int H, int W, const float* coef9, void* stream);
 /* metrics_out: fp32 [2] = mean soft Dice (1 - DiceLoss), mean hard IoU at thr            */
 int aau_seg_metrics(const float* logits, const float* targets, float* sums, float* metrics_out,
                     int B, int H, int W, float thr, void* stream);
+
+/* Integer counts behind eval_segmentation_batch.py:41-49 (`_bin`: a > 0; `dice`, `iou`):     */
+/* out3 (device, uint64 [3], zeroed by the call) = |a|, |b|, |a & b| over n elements; a / b are  */
+/* uint8 masks or fp32 arrays (x_is_f32).  Exact: the quotients are formed on the host in fp64. */
+int aau_seg_counts(const void* a, int a_is_f32, const void* b, int b_is_f32, int64_t n,
+                   uint64_t* out3, void* stream);
 
 /* ---- optimiser (pipeline:302 AdamW, :323 clip_grad_norm_) ------------------------------ */
 /* norm_ws: fp32 [1] zeroed by the call; accumulates sum of squares of grad*inv_scale       */
@@ -312,6 +336,15 @@ int aau_grad_sqnorm(const float* grad, int64_t n, float inv_scale, float* norm_w
 int aau_adamw_step(float* p, float* m, float* v, const float* g, int64_t n,
                    const float* norm_ws, int64_t* step_dev, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float max_norm, float inv_scale, void* stream);
+
+/* The same update with lr / weight_decay read from DEVICE memory at run time, so a captured    */
+/* hipGraph follows the LR schedule (pipeline:303-306,325), and one (lr, weight_decay) pair per   */
+/* parameter group: hyp fp32 [n_groups][2]; group_of_block: group id of every 64-element block   */
+/* of the flat buffers (null when n_groups == 1).  Differential LR: test_ablation.py:576-586.    */
+int aau_adamw_step_dev(float* p, float* m, float* v, const float* g, int64_t n, const float* norm_ws,
+                       int64_t* step_dev, const float* hyp, const unsigned char* group_of_block,
+                       int n_groups, float beta1, float beta2, float eps, float max_norm,
+                       float inv_scale, void* stream);
 
 /* ---- small utilities -------------------------------------------------------------------- */
 int aau_f32_to_bf16(const float* src, aau_bf16* dst, int64_t n, void* stream);

@@ -29,11 +29,17 @@ def main():
     kib = lambda rows: sum(float(r["Counter_Value"]) for r in rows) * 1024.0
     n_conv = sum(1 for r in rd if is_conv(r) and "wg_reduce" not in r["Kernel_Name"])
     conv_rd, conv_wr = 2.0 * kib([r for r in rd if is_conv(r)]), kib([r for r in wr if is_conv(r)])
-    by = {}
+    by, nl = {}, {}
     for rows, mul in ((rd, 2.0), (wr, 1.0)):
         for r in rows:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("aau::", "")
             by[k] = by.get(k, 0.0) + mul * float(r["Counter_Value"]) * 1024.0
+            if mul == 2.0:
+                nl[k] = nl.get(k, 0) + 1
+
+    def canon(k):   # "conv3x3g_kernel<96>" -> "conv3x3g<96>" (the tag bench.py's live profiler reports)
+        k = k.replace("_kernel", "").replace(" ", "").replace("false", "0").replace("true", "1")
+        return "wgrad3x3<3,8>" if k.startswith("wgrad3x3<3,8") else k
     res = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --graph 0; last step",
         "correction": "FETCH_SIZE x 1024 B x 2 (gfx950 counts 128-B read requests as 64 B on wide coalesced streams), WRITE_SIZE x 1024 B",
@@ -41,6 +47,9 @@ def main():
                          "bytes_per_launch": (conv_rd + conv_wr) / max(n_conv, 1)},
         "whole_step": {"read_bytes": 2.0 * kib(rd), "write_bytes": kib(wr)},
         "bytes_by_kernel": dict(sorted(by.items(), key=lambda kv: -kv[1])),
+        "by_kernel": {canon(k): {"bytes_per_step": v, "launches_per_step": nl.get(k, 0),
+                                 "bytes_per_launch": v / max(nl.get(k, 1), 1)}
+                      for k, v in sorted(by.items(), key=lambda kv: -kv[1])},
     }
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["conv_kernels"]), json.dumps(res["whole_step"]))
