@@ -56,6 +56,8 @@ _SIGS = {
     "aau_conv_igemm_bnred": [C.POINTER(ConvDesc), P, P, P, P, I, P, P, P, P, P, P],
     "aau_conv_wgrad": [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P],
     "aau_conv_wgrad_ws_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int64)],
+    "aau_conv_wgrad_group_ok": [C.POINTER(ConvDesc), I],
+    "aau_conv_wgrad_group": [C.POINTER(ConvDesc), P, P, P, I, P],
     "aau_conv1_fwd": [P, P, P, P, I, I, I, I, P],
     "aau_conv1_wgrad": [P, P, P, I, I, I, I, P],
     "aau_pack_weights": [P, P, P, I, L, P],

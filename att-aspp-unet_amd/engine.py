@@ -405,7 +405,8 @@ class Plan:
         return rec
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
-    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, feeds=None, din_stats=None):
+    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, feeds=None, din_stats=None,
+                defer_wgrad=None):
         """``feeds``: record of the ConvBNReLU whose output is this layer's ONLY consumer input (din is its full
         output gradient): its BatchNorm-backward reduce is then fused into this layer's data-gradient epilogue."""
         cv, bn, w = r["cv"], r["bn"], r["w"]
@@ -451,7 +452,10 @@ class Plan:
             b.add("aau_conv1_wgrad", r["src"], dz, cv.dw, N, H, W, cv.O, side=ov)
             return dz
         dwd = ops.conv_desc(N, H, W, cv.I, r["sp"], H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil)
-        b.add_wgrad(dwd, r["src"], dz, cv.dw, side=ov)
+        if defer_wgrad is not None:
+            defer_wgrad.append((dwd, r["src"], dz, cv.dw, b.label))     # emitted later as one grouped launch
+        else:
+            b.add_wgrad(dwd, r["src"], dz, cv.dw, side=ov)
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate)
@@ -675,10 +679,25 @@ class Plan:
             mark(blk["name"])
         # bridge
         dcat5 = self.new(M5, ncat)
-        self.cbr_bwd(rproj, dy, Cb, din=dcat5, dinp=ncat)
+        # the weight gradients of the projection and of the spatial branches go into ONE grouped launch
+        # (aau_conv_wgrad_group) once every branch's dz exists; their data gradients run as before
+        wg = [] if not eng.no_wgrad_group else None
+        self.cbr_bwd(rproj, dy, Cb, din=dcat5, dinp=ncat, defer_wgrad=wg)
         dp4 = self.new(M5, Cs[3])
         for i, r in enumerate(br):
-            self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0)
+            self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0, defer_wgrad=wg)
+        if wg:
+            descs = [w_[0] for w_ in wg]
+            b.label = "bridge(grouped)"
+            if len(wg) <= 8 and ops.conv_wgrad_group_ok(descs):
+                pack = ops.wgrad_group_args(descs, [w_[1] for w_ in wg], [w_[2] for w_ in wg], [w_[3] for w_ in wg])
+                b.keep.extend([w_[k] for w_ in wg for k in (1, 2, 3)])
+                b.keep.append(pack)
+                b.add("aau_conv_wgrad_group", *pack)
+            else:
+                for dwd, src, dz_, dw_, lab in wg:
+                    b.label = lab
+                    b.add_wgrad(dwd, src, dz_, dw_)
         dpb = self.new(B, Cb)
         b.label = "bridge.pool"
         b.add("aau_spatial_sum", dcat5[:, nbr * Cb:], ncat, dpb, gap_ws, B, h5 * w5, Cb)
@@ -755,6 +774,7 @@ class Engine:
         self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switches
         self.no_fuse_colsum = os.environ.get("AAU_NO_FUSE_COLSUM", "0") == "1"
         self.no_fuse_head = os.environ.get("AAU_NO_FUSE_HEAD", "0") == "1"
+        self.no_wgrad_group = os.environ.get("AAU_NO_WGRAD_GROUP", "0") == "1"
         # z of the first layer recomputed from the frame instead of stored (-201 MB of HBM at bs 8 / 512^2): measured
         # 0.08 ms SLOWER per step (the three recomputing kernels are VALU / latency bound, not byte bound), so opt-in
         self.no_recompute_z1 = os.environ.get("AAU_RECOMPUTE_Z1", "0") != "1" or self.no_fuse_conv1

@@ -84,6 +84,27 @@ def conv_wgrad(desc: ConvDesc, src, dz, dw, ws=None):
     check(fn("aau_conv_wgrad")(C.byref(desc), _p(src), _p(dz), _p(dw), _p(ws), nb, _stream()), "aau_conv_wgrad")
 
 
+def wgrad_group_args(descs, srcs, dzs, dws):
+    """ctypes argument pack of aau_conv_wgrad_group (keep the returned tuple alive while the call may run)."""
+    n = len(descs)
+    da = (ConvDesc * n)(*descs)
+    sa = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    za = (C.c_void_p * n)(*[t.data_ptr() for t in dzs])
+    wa = (C.c_void_p * n)(*[t.data_ptr() for t in dws])
+    return da, sa, za, wa, n
+
+
+def conv_wgrad_group_ok(descs) -> bool:
+    n = len(descs)
+    return bool(fn("aau_conv_wgrad_group_ok")((ConvDesc * n)(*descs), n))
+
+
+def conv_wgrad_group(descs, srcs, dzs, dws):
+    """dw_i += weight gradient of problem i, all problems in one launch (see include/aau.h)."""
+    da, sa, za, wa, n = wgrad_group_args(descs, srcs, dzs, dws)
+    check(fn("aau_conv_wgrad_group")(da, sa, za, wa, n, _stream()), "aau_conv_wgrad_group")
+
+
 def conv1_fwd(x, w, z, stats, N, H, W, Cc):
     check(fn("aau_conv1_fwd")(_p(x), _p(w), _p(z), _p(stats), N, H, W, Cc, _stream()), "aau_conv1_fwd")
 

@@ -124,6 +124,17 @@ int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    float* dw, float* ws, int64_t ws_bytes, void* stream);
 int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes);
 
+/* Grouped weight gradient: n (<= 8) problems tiled into ONE grid of 192 x 192 (q x c) tiles, every     */
+/* tile over the full pixel range (no split-K workspace, bitwise reproducible), dw_i += result.        */
+/* Built for the ASPP bridge (pipeline:67-83: blocks[0..3] and project share their input / gradient     */
+/* tensors): three dilated 3x3 + 1x1 + the 5C -> C projection in one launch.  Each problem must be a    */
+/* 1x1/stride-1 conv or have Wo % 32 == 0 (K-steps are 32-pixel row segments; steps whose source row is  */
+/* outside the image are skipped); aau_conv_wgrad_group_ok says whether the group is in range AND large   */
+/* enough to fill the chip (otherwise use aau_conv_wgrad per problem).                                  */
+int aau_conv_wgrad_group_ok(const aau_conv_desc* descs, int n);
+int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* const* srcs,
+                         const aau_bf16* const* dzs, float* const* dws, int n, void* stream);
+
 /* Traversal hint (per calling thread).  alternate = 1: from now on every launch of the large  */
 /* streaming kernels (BN / pool / first and last layer / 3x3 and 1x1 convs / weight grads)    */
 /* walks its tensors in the direction OPPOSITE to the previous such launch, starting with     */

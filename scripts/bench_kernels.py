@@ -153,3 +153,24 @@ for name, ho, Co in GATES:
         line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     print(line, flush=True)
 print("totals (us):", {k: round(v, 1) for k, v in tot.items()})
+# ---- the ASPP bridge weight gradients as ONE grouped launch (csrc/wgradL.hip) vs the per-problem kernels ----
+if not a.only or "bridge" in a.only or "br." in a.only:
+    H, Ci, Co = 32, 384, 768
+    M = B * H * H
+    x = torch.randn(B, H, H, Ci, device="cuda").to(torch.bfloat16)
+    cat = torch.randn(B, H, H, 5 * Co, device="cuda").to(torch.bfloat16)
+    dcat = torch.randn(B, H, H, 5 * Co, device="cuda").to(torch.bfloat16)
+    dzp = torch.randn(B, H, H, Co, device="cuda").to(torch.bfloat16)
+    descs, srcs, dzs, dws, gf = [], [], [], [], 0.0
+    for i, (k, dil) in enumerate(((1, 1), (3, 6), (3, 12), (3, 18))):
+        descs.append(ops.conv_desc(B, H, H, Ci, Ci, H, H, Co, 5 * Co, k, k, 1, dil * (k // 2), dil))
+        srcs.append(x); dzs.append(dcat[..., i * Co:]); dws.append(torch.zeros(Co, k * k, Ci, device="cuda"))
+        gf += 2.0 * M * Ci * Co * k * k / 1e9
+    descs.append(ops.conv_desc(B, H, H, 5 * Co, 5 * Co, H, H, Co, Co))
+    srcs.append(cat); dzs.append(dzp); dws.append(torch.zeros(Co, 1, 5 * Co, device="cuda"))
+    gf += 2.0 * M * 5 * Co * Co / 1e9
+    if ops.conv_wgrad_group_ok(descs):
+        t = timeit(lambda: ops.conv_wgrad_group(descs, srcs, dzs, dws))
+        t0 = timeit(lambda: [wgrad(d_, s_, z_, w_) for d_, s_, z_, w_ in zip(descs, srcs, dzs, dws)])
+        print(f"bridge wgrad (1x1 + d6 + d12 + d18 + proj) {gf:7.1f} GF | grouped {t:7.1f} us {gf / t * 1e3:6.0f} TF (dense-equivalent) | "
+              f"per-problem kernels {t0:7.1f} us {gf / t0 * 1e3:6.0f} TF", flush=True)

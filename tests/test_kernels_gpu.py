@@ -356,3 +356,74 @@ def test_wgrad_convT(ops, mode):
     torch.cuda.synchronize()
     got = dw.cpu().reshape(Ci, 2, 2, Co).permute(0, 3, 1, 2)
     assert rel_err(got, ref) < 2e-3
+
+
+# ---- grouped big-tile weight gradient (aau_conv_wgrad_group, csrc/wgradL.hip) ----
+def _group_problem(ops, N, H, W, Cin, Cout, k, dil, seed, x=None, xpitch=None, zpitch=None):
+    g = torch.Generator().manual_seed(seed)
+    if x is None:
+        x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
+    dy = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    ref = R.conv_wgrad(x, dy, (Cout, Cin, k, k), dil)
+    xp, zp = xpitch or Cin, zpitch or Cout
+    xd = torch.zeros(N, H, W, xp, dtype=torch.bfloat16, device="cuda")
+    xd[..., xp - Cin:] = x.to(torch.bfloat16).cuda()                 # the tensor is a channel slice of a wider buffer
+    zd = torch.zeros(N, H, W, zp, dtype=torch.bfloat16, device="cuda")
+    zd[..., :Cout] = dy.to(torch.bfloat16).cuda()
+    d = ops.conv_desc(N, H, W, Cin, xp, H, W, Cout, zp, k, k, 1, dil * (k // 2), dil)
+    dw = torch.zeros(Cout, k * k, Cin, device="cuda")
+    return dict(d=d, src=xd[..., xp - Cin:], dz=zd[..., :Cout], dw=dw, ref=ref, x=x, k=k)
+
+
+def _check_group(ops, probs, tol=2e-3):
+    ops.conv_wgrad_group([p["d"] for p in probs], [p["src"] for p in probs], [p["dz"] for p in probs], [p["dw"] for p in probs])
+    torch.cuda.synchronize()
+    for p in probs:
+        Cout, T, Cin = p["dw"].shape
+        got = p["dw"].cpu().reshape(Cout, p["k"], p["k"], Cin).permute(0, 3, 1, 2)
+        assert rel_err(got, p["ref"]) < tol, (Cout, Cin, p["k"], rel_err(got, p["ref"]))
+    # dw += : a second call doubles the result, bitwise reproducibly
+    first = [p["dw"].clone() for p in probs]
+    ops.conv_wgrad_group([p["d"] for p in probs], [p["src"] for p in probs], [p["dz"] for p in probs], [p["dw"] for p in probs])
+    torch.cuda.synchronize()
+    for p, f in zip(probs, first):
+        assert rel_err(p["dw"].cpu(), 2 * f.cpu()) < 1e-6
+        z = torch.zeros_like(f)
+        ops.conv_wgrad_group([p["d"]], [p["src"]], [p["dz"]], [z])
+        assert torch.equal(z, f)
+
+
+def test_wgrad_group_small_ragged_shapes(ops):
+    """Tile tails in both channel dimensions, dilation skipping, pitched operands, a strided 2x2 problem."""
+    probs = [
+        _group_problem(ops, 2, 16, 32, 104, 200, 3, 2, 1, xpitch=136, zpitch=208),
+        _group_problem(ops, 2, 16, 32, 200, 104, 1, 1, 2),
+        _group_problem(ops, 1, 32, 64, 96, 96, 3, 6, 3),                       # two 32-pixel segments per row
+        _group_problem(ops, 4, 16, 16, 192, 384, 1, 1, 4, zpitch=768),         # linear: W need not be a multiple of 32
+    ]
+    _check_group(ops, probs)
+    # ConvTranspose2d(2,2) weight gradient as the engine states it: "x" = fine-grid gradient, "dz" = coarse input
+    N, H, W, Ci, Co = 1, 32, 32, 128, 96
+    g = torch.Generator().manual_seed(31)
+    x = R.bf16_round(torch.randn(N, H, W, Ci, generator=g))
+    dy = R.bf16_round(torch.randn(N, 2 * H, 2 * W, Co, generator=g))
+    ref = R.convT_wgrad(x, dy, torch.zeros(Ci, Co, 2, 2))
+    d = ops.conv_desc(N, 2 * H, 2 * W, Co, Co, H, W, Ci, Ci, 2, 2, 2, 0, 1)
+    dw = torch.zeros(Ci, 4, Co, device="cuda")
+    ops.conv_wgrad_group([d], [dev(dy.to(torch.bfloat16))], [dev(x.to(torch.bfloat16))], [dw])
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu().reshape(Ci, 2, 2, Co).permute(0, 3, 1, 2), ref) < 2e-3
+
+
+def test_wgrad_group_at_the_real_bridge_shape(ops):
+    """8 x 32 x 32, 384 -> 768: 1x1 + dilation 6 / 12 / 18 on ONE input, and the 3840 -> 768 projection, as one launch
+    (what engine.py records for the ASPP bridge at base_c 48)."""
+    N, H, W, Ci, Co = 8, 32, 32, 384, 768
+    first = _group_problem(ops, N, H, W, Ci, Co, 1, 1, 11, zpitch=5 * Co)
+    probs = [first]
+    for i, dil in enumerate((6, 12, 18)):
+        probs.append(_group_problem(ops, N, H, W, Ci, Co, 3, dil, 12 + i, x=first["x"], zpitch=5 * Co))
+        probs[-1]["src"] = first["src"]                                       # the branches share their input tensor
+    probs.append(_group_problem(ops, N, H, W, 5 * Co, Co, 1, 1, 20))
+    assert ops.conv_wgrad_group_ok([p["d"] for p in probs])
+    _check_group(ops, probs)
