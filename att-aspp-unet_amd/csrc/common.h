@@ -15,6 +15,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// ---- transposed LDS reads as inline asm --------------------------------------------------------------------------
+// hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the ds_read_tr BUILTIN whenever an LDS-DMA
+// (buffer_load ... lds / global_load_lds) is in flight: it treats the builtin as a read of memory the DMA may still be
+// writing and cannot tell the ring slots apart.  That drains the prefetch of the NEXT K-step before the MFMAs of the
+// current one start, i.e. no load / compute overlap inside a workgroup (plain ds_read_b128 loads do not trigger it).
+// The compiler does not look inside an asm statement, so the kernels' own counted vmcnt + barrier stay the only
+// wait.  What the asm form costs: the reads are invisible to hipcc's lgkmcnt bookkeeping as well, so every use sits
+// behind an explicit AAU_LGKM_WAIT that names the destinations ("+v"; guide 5.7 item 1, form ii).
+#define AAU_TR16(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
+#define AAU_FRAG8(lo, hi) __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
+// 32-bit LDS byte address of a __shared__ object (generic -> LDS address space)
+#define AAU_LDS_ADDR(p) ((unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)(p))
+
 namespace aau {
 
 // 16-B loads of out-of-image taps / rows past the tensor are redirected to this page

@@ -581,6 +581,248 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENT (opt-in, AAU_C3_LOADER=1; measured 25-30 % slower than conv3x3g, see conv3x3_launch):
+// the grouped-tap kernel with a DEDICATED LOADER WAVE (wave 4 of 5).  In conv3x3g every wave issues its share of the
+// LDS-DMA (~5 buffer_load ... lds per step); inside a wave that also runs 48 MFMAs and 20 ds_read_b128 per step each
+// of them costs 100-185 cycles of that wave's in-order stream, i.e. ~40 % on top of the 768 MFMA cycles -- which is
+// the measured 44 % MFMA utilisation.  A wave that does nothing else issues a 1-KiB piece every ~20 cycles (guide:
+// ldsdma-fill), so one loader wave per workgroup carries all 12 weight + 21 halo pieces of a step, waits for them
+// with its OWN vmcnt, and releases the four MFMA waves through the step barrier; the MFMA waves issue no VMEM at all
+// in the loop.  154 VGPRs -> 3 waves per SIMD -> two 5-wave workgroups per CU as before (67 KB LDS each).
+template <int BQ>
+__global__ __launch_bounds__(320) void conv3x3l_kernel(const C3Args a) {
+    constexpr int BK = 32, HW_ = 18, HROWS = 324, HPAD = 336, NI = BQ / 16, MI = 4;
+    constexpr int HALO_E = HPAD * BK, WT_E = BQ * BK, SLOT_E = 2 * WT_E;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned short c3l_smem[];   // 2 halo buffers + 3 weight slots: 78 KB
+    unsigned short* smem = c3l_smem;
+    auto sH = [&](int b) -> unsigned short* { return smem + b * HALO_E; };
+    auto sWt = [&](int slot, int k) -> unsigned short* { return smem + 2 * HALO_E + slot * SLOT_E + k * WT_E; };
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int ntq = (d.Cout + BQ - 1) / BQ;
+    const int nwg = gridDim.x;
+    int bid = a.rev ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tq = bid % ntq;
+    int patch = bid / ntq;
+    const int px_t = patch % a.tiles_x;
+    patch /= a.tiles_x;
+    const int py_t = patch % a.tiles_y;
+    const int n = patch / a.tiles_y;
+    const int q0 = tq * BQ, y0 = py_t * 16, x0 = px_t * 16;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+
+    const bool loader = wave == 4;
+    f32x4 acc[NI][MI];     // zeroed on the MFMA waves' path only: the loader wave must not carry 96 dead registers
+    const int fr = lane & 15, fk = lane >> 4;
+    auto compute_tap = [&](const unsigned short* hbase, const unsigned short* wbase, int tap) {
+        const int ty = tap / 3, tx = tap - ty * 3;
+        bf16x8 wf[NI], af[MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int row = ni * 16 + fr;
+            wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
+            af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
+        }
+        // raised priority keeps the MFMA cluster together (A/B: +3-7 % here; the same pair costs
+        // wgrad3x3_kernel 6-9 %, so it is not used there)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- pipeline over S = nchunk * 5 steps; weights one step ahead, next halo issued AFTER them at group 0 ----
+    // loader: wait (own vmcnt) until step s's tiles landed -> barrier s -> issue step s+1 (its slot was read in step
+    // s-1, which every MFMA wave finished before arriving at barrier s).  MFMA waves: barrier s -> compute step s.
+    const int S = a.nchunk * 5;
+    int chunk = 0, g = 0, slot = 0;
+    if (loader) {
+        // halo: 21 wave-instructions of 16 rows, all issued by the loader wave
+        constexpr int HI = 21;
+        unsigned hoff[HI];
+        bool htail[HI];
+        const int tail_c0 = (a.nchunk - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < HI; ++i) {
+            const int hr = i * 16 + (lane >> 2);
+            const int lc = swz32(hr, lane & 3);
+            const int hy = hr / HW_, hx = hr - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = hr < HROWS && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+            hoff[i] = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc * 8) * 2) : OOB;
+            htail[i] = tail_c0 + lc * 8 < d.Cin;
+        }
+        const bool has_tail = d.Cpad != d.Cin;
+        constexpr int WI = BQ / 16;       // weight-tile pieces of 16 rows (BQ = 48 / 96: whole pieces)
+        static_assert(BQ % 16 == 0, "weight tile in whole 16-row pieces");
+        unsigned woff[WI];
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            const int row = j * 16 + (lane >> 2);
+            const int lc = swz32(row, lane & 3);
+            woff[j] = (q0 + row) < d.Cout ? (unsigned)(((q0 + row) * 9 * d.Cpad + lc * 8) * 2) : OOB;
+        }
+        auto issue_halo = [&](int chunk) {
+            const bool last = has_tail && chunk == a.nchunk - 1;
+            unsigned short* base = sH(chunk & 1);
+#pragma unroll
+            for (int i = 0; i < HI; ++i) {
+                const unsigned v = (last && !htail[i]) ? OOB : hoff[i];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base + i * 16 * BK), 16, (int)v, chunk * BK * 2, 0, 0);
+            }
+        };
+        // group g of a chunk = taps {2g, 2g+1} for g < 4, {8} for g == 4.  ALWAYS 2 * WI pieces (the missing tap of group
+        // 4 is loaded as zeros through out-of-range offsets) so that the loader's vmcnt counts are constants.
+        auto issue_w = [&](int slot, int chunk, int g) {
+            const int t0 = 2 * g, nt = (g == 4) ? 1 : 2;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int soff = k < nt ? ((t0 + k) * d.Cpad + chunk * BK) * 2 : 0;
+                unsigned short* base = sWt(slot, k);
+#pragma unroll
+                for (int j = 0; j < WI; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(base + j * 16 * BK), 16,
+                                                             (int)(k < nt ? woff[j] : OOB), soff, 0, 0);
+            }
+        };
+        // Three weight slots: the group of step s+2 is issued right after barrier s (its slot was read in step s-1), so
+        // it has a whole MFMA step to land and its issue time overlaps the MFMA waves' step s.  Issue order:
+        // halo(0) w(0) w(1) | iteration s: w(s+2), then halo(chunk+1) when s is the first step of a chunk.
+        // Loads younger than w(s) at the top of iteration s: w(s+1) and at most one halo tile (issued right after w(s)
+        // or right after w(s+1)): 12 or 33 pieces may stay in flight (vmcnt retires in order).
+        static_assert(2 * WI == 12 || 2 * WI == 6, "wait counts below");
+        issue_halo(0);
+        issue_w(0, 0, 0);
+        if (S > 1) issue_w(1, 0, 1);
+        int g2 = 2, c2 = 0, islot = 2;          // (chunk, group, slot) of step s + 2
+        bool halo_m1 = false, halo_m2 = false;   // iterations s-1 / s-2 issued a halo tile
+        for (int s = 0; s < S; ++s) {
+            if (s + 1 >= S) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (halo_m1 || halo_m2) {
+                if constexpr (WI == 6) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+            } else {
+                if constexpr (WI == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            halo_m2 = halo_m1;
+            halo_m1 = false;
+            if (s + 2 < S) {
+                issue_w(islot, c2, g2);
+                if (++g2 == 5) { g2 = 0; ++c2; }
+                islot = islot == 2 ? 0 : islot + 1;
+            }
+            if (g == 0 && chunk + 1 < a.nchunk) { issue_halo(chunk + 1); halo_m1 = true; }
+            if (++g == 5) { g = 0; ++chunk; }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) {
+            __builtin_amdgcn_s_barrier();
+            const unsigned short* hbase = sH(chunk & 1);
+            compute_tap(hbase, sWt(slot, 0), 2 * g);
+            if (g < 4) compute_tap(hbase, sWt(slot, 1), 2 * g + 1);
+            if (++g == 5) { g = 0; ++chunk; }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    }
+
+    // ---- epilogue (as conv3x3_kernel) ----
+    const bool want_stats = a.stats != nullptr;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        if (loader) break;          // wave-uniform
+        const int y = y0 + wave * MI + mi, x = x0 + fr;
+        const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int q = q0 + ni * 16 + 4 * fk;
+            if (q >= d.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+            if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
+            if (a.bias) {
+                const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (a.scale) {
+                const f32x4 sc = *(const f32x4*)(a.scale + q);
+                const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+            }
+            unsigned short* out = a.dst + pixel * d.dst_pitch + q;
+            if (d.accumulate) {
+                const u32x2 old = *(const u32x2*)out;
+                v[0] += __uint_as_float(old[0] << 16);
+                v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                v[2] += __uint_as_float(old[1] << 16);
+                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+            }
+            if (d.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            u32x2 pk;
+            pk[0] = pack2(v[0], v[1]);
+            pk[1] = pack2(v[2], v[3]);
+            *(u32x2*)out = pk;
+        }
+    }
+    if (want_stats) {
+        float* sst = (float*)smem;
+        __syncthreads();
+        if (tid < 2 * BQ) sst[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0 && !loader) {
+                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
+                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                }
+            }
+        }
+        __syncthreads();
+        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+        if (tid < 2 * BQ) {
+            const int which = tid / BQ, ql = tid - which * BQ;
+            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Resident-weight variant for the high-resolution, few-channel layers (d1.1, d2.0, u1.conv.*):
 // there the whole packed weight matrix of a channel tile (<= 110 KB) fits in LDS next to two halo
 // buffers, K is short (18-27 steps) and the per-workgroup prologue / epilogue of the kernel above
@@ -1329,6 +1571,21 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     if (wide_patch) a.tiles_x = d->W / 32;
     const int64_t grid = (int64_t)((d->Cout + BQ - 1) / BQ) * a.tiles_x * a.tiles_y * d->N;
     if (grid <= 0 || grid > 0x7fffffff) { set_error("conv3x3: grid out of range"); return AAU_E_INVALID; }
+    // loader-wave variant: measured 25-30 % SLOWER than conv3x3g on every layer (A/B in one gpurun call, 2- and 3-slot
+    // weight rings alike), so it is opt-in (experiments only)
+    if (!wide_patch && !getenv("AAU_C3_NOGROUP") && getenv("AAU_C3_LOADER")) {
+        prof_tag(narrow ? "conv3x3l<48>" : "conv3x3l<96>");
+        static bool attrl = false;
+        if (!attrl) {
+            hipFuncSetAttribute((const void*)conv3x3l_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv3x3l_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attrl = true;
+        }
+        const size_t ldsl = (size_t)(2 * 336 * 32 + 3 * 2 * BQ * 32) * 2;
+        if (narrow) hipLaunchKernelGGL((conv3x3l_kernel<48>), dim3((unsigned)grid), dim3(320), ldsl, s, a);
+        else hipLaunchKernelGGL((conv3x3l_kernel<96>), dim3((unsigned)grid), dim3(320), ldsl, s, a);
+        return check_launch("aau_conv_igemm(3x3 halo, grouped taps, loader wave)");
+    }
     prof_tag(narrow ? "conv3x3g<48>" : "conv3x3g<96>");
     if (!wide_patch && !getenv("AAU_C3_NOGROUP")) {
         if (narrow) hipLaunchKernelGGL((conv3x3g_kernel<48>), dim3((unsigned)grid), dim3(256), 0, s, a);

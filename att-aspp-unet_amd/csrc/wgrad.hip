@@ -173,34 +173,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     // transposed-read addressing: lane 4*rq+p of a 16-lane group supplies row rq, columns 4p..4p+3
     const int g16 = lane >> 4, li = lane & 15;
     const int rq = li >> 2, cp = (li & 3) * 4;
+    // transposed reads in asm form (common.h, AAU_TR16): the builtin made hipcc drain the next K-step's LDS-DMA first
+    const unsigned lds_base = AAU_LDS_ADDR(smem);
     auto compute = [&](int buf) {
+        const unsigned by = lds_base + buf * (YB + XB);
+        const unsigned bx = by + YB;
 #pragma unroll
         for (int ks = 0; ks < KSUBW; ++ks) {
             const int rbase = (wk * KSUBW + ks) * 32 + 4 * g16 + rq;
-            bf16x8 af[3], bf[3];
+            u32x2 alo[3], ahi[3], blo[3], bhi[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int ch = wq * 48 + i * 16 + cp;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(sY(buf) + tile_off<TQ>(rbase, ch)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(sY(buf) + tile_off<TQ>(rbase + 16, ch)));
-                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                AAU_TR16(alo[i], by + tile_off<TQ>(rbase, ch));
+                AAU_TR16(ahi[i], by + tile_off<TQ>(rbase + 16, ch));
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int ch = wc * 48 + j * 16 + cp;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(sX(buf) + tile_off<TC>(rbase, ch)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(sX(buf) + tile_off<TC>(rbase + 16, ch)));
-                bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                AAU_TR16(blo[j], bx + tile_off<TC>(rbase, ch));
+                AAU_TR16(bhi[j], bx + tile_off<TC>(rbase + 16, ch));
             }
+            // in-order LDS returns: everything but the last two column fragments first, then those
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(ahi[0]), "+v"(ahi[1]),
+                         "+v"(ahi[2]), "+v"(blo[0]), "+v"(bhi[0]));
+            const bf16x8 af0 = AAU_FRAG8(alo[0], ahi[0]), af1 = AAU_FRAG8(alo[1], ahi[1]), af2 = AAU_FRAG8(alo[2], ahi[2]);
+            {
+                const bf16x8 bf = AAU_FRAG8(blo[0], bhi[0]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf, acc[1][0], 0, 0, 0);
+                acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2, bf, acc[2][0], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]));
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 1; j < 3; ++j) {
+                const bf16x8 bf = AAU_FRAG8(blo[j], bhi[j]);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf, acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf, acc[1][j], 0, 0, 0);
+                acc[2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2, bf, acc[2][j], 0, 0, 0);
+            }
         }
     };
 

@@ -158,12 +158,15 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
     const int rq = li >> 2, cp = (li & 3) * 4;   // transposed read: lane supplies row rq, columns cp..cp+3
     const int yrow = 4 * g16 + rq;                               // dz row inside a 16-pixel patch row
     const int xbase = (4 * g16 + rq) * 96 + cp * 2;              // + (2*ss + h)*18*96 + coff[n]
+    // Transposed reads in asm form (common.h, AAU_TR16): with the builtin hipcc drained the LDS-DMA of the NEXT patch
+    // (issued just above) with a vmcnt(0) before the first read, so staging and MFMAs never overlapped.
+    const unsigned lds_base = AAU_LDS_ADDR(smem);
     auto compute = [&](int buf) {
-        const unsigned char* by = sY(buf);
-        const unsigned char* bx = sX(buf);
+        const unsigned by = lds_base + buf * (YB + XB);
+        const unsigned bx = by + YB;
 #pragma unroll
         for (int ss = 0; ss < PR / 2; ++ss) {
-            bf16x8 af[QW];
+            u32x2 alo[QW], ahi[QW], blo[7], bhi[7];
 #pragma unroll
             for (int i = 0; i < QW; ++i) {
                 const int r0 = (2 * ss) * 16 + yrow, r1 = r0 + 16;
@@ -176,21 +179,42 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
                     o0 = r0 * 192 + ((gi ^ ((r0 >> 2) & 1)) * 32) + cp * 2;
                     o1 = r1 * 192 + ((gi ^ ((r1 >> 2) & 1)) * 32) + cp * 2;
                 }
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o0));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(by + o1));
-                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                AAU_TR16(alo[i], by + o0);
+                AAU_TR16(ahi[i], by + o1);
             }
 #pragma unroll
-            for (int n = 0; n < 7; ++n) {
-                if (n < nct) {   // wave-uniform
-                    const int o = xbase + (2 * ss) * 18 * 96 + coff[n];
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bx + o));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bx + o + 18 * 96));
-                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            for (int n = 0; n < 7; ++n) {      // the 4th wave's 7th tile is a duplicate (ct clamped): read, never used
+                const unsigned o = bx + xbase + (2 * ss) * 18 * 96 + coff[n];
+                AAU_TR16(blo[n], o);
+                AAU_TR16(bhi[n], o + 18 * 96);
+            }
+            // LDS returns in order: all but the youngest 8 reads (column tiles 3..6) are back
+            if constexpr (QW == 3) {
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(ahi[0]), "+v"(ahi[1]),
+                             "+v"(ahi[2]), "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]));
+            } else {
+                static_assert(QW == 3 || QW == 6, "operand lists of the waits");
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3 % QW]), "+v"(alo[4 % QW]),
+                             "+v"(alo[5 % QW]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]), "+v"(ahi[3 % QW]), "+v"(ahi[4 % QW]),
+                             "+v"(ahi[5 % QW]), "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]));
+            }
+            bf16x8 af[QW];
 #pragma unroll
-                    for (int i = 0; i < QW; ++i)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
-
+            for (int i = 0; i < QW; ++i) af[i] = AAU_FRAG8(alo[i], ahi[i]);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const bf16x8 bf = AAU_FRAG8(blo[n], bhi[n]);
+#pragma unroll
+                for (int i = 0; i < QW; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[3]), "+v"(blo[4]), "+v"(blo[5]), "+v"(blo[6]), "+v"(bhi[3]),
+                         "+v"(bhi[4]), "+v"(bhi[5]), "+v"(bhi[6]));
+#pragma unroll
+            for (int n = 3; n < 7; ++n) {
+                if (n < nct) {   // wave-uniform
+                    const bf16x8 bf = AAU_FRAG8(blo[n], bhi[n]);
+#pragma unroll
+                    for (int i = 0; i < QW; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
                 }
             }
         }

@@ -9,7 +9,7 @@ The class is a ``torch.optim.Optimizer`` so the reference's LR schedulers
 The learning rate and weight decay of every parameter group live in DEVICE memory
 (``hyp`` [G, 2]); the kernel reads them at run time, so a step captured into a hipGraph
 follows the schedule: ``refresh_hyper()`` uploads the current ``param_groups`` values
-whenever they changed (a 16-byte pinned-host copy on the stream, issued OUTSIDE of
+whenever they changed (a 16-byte host-to-device copy on the stream, issued OUTSIDE of
 capture).  Several groups (test_ablation.py:576-586: attention parameters at the full rate,
 backbone at half) are resolved per 64-element block of the flat buffer by a byte table.
 """
@@ -37,7 +37,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise _abi.AauError(f"FusedAdamW: parameters in no group: {missing[:4]}{' ...' if len(missing) > 4 else ''}")
         if len(self.param_groups) > 256:
             raise _abi.AauError("FusedAdamW: at most 256 parameter groups")
-        self._hyp_dev = self._hyp_host = self._gob = None
+        self._hyp_dev = self._gob = None
         self._hyp_last = None
         self._store_id = None
 
@@ -50,7 +50,6 @@ class FusedAdamW(torch.optim.Optimizer):
             st.v = torch.zeros_like(st.flat)
         if self._store_id != id(st):
             G = len(self.param_groups)
-            self._hyp_host = torch.zeros(G, 2, dtype=torch.float32).pin_memory()
             self._hyp_dev = torch.zeros(G, 2, dtype=torch.float32, device=st.device)
             self._hyp_last = None
             self._gob = None
@@ -70,9 +69,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self._store()
         cur = tuple((float(g["lr"]), float(g["weight_decay"])) for g in self.param_groups)
         if cur != self._hyp_last:
-            for k, (lr, wd) in enumerate(cur):
-                self._hyp_host[k, 0], self._hyp_host[k, 1] = lr, wd
-            self._hyp_dev.copy_(self._hyp_host, non_blocking=True)
+            # a fresh pageable source per upload: the copy is staged at call time, so a later change of the schedule can
+            # never overwrite the values of an upload the stream has not executed yet (a reused pinned buffer can)
+            self._hyp_dev.copy_(torch.tensor(cur, dtype=torch.float32).view(len(cur), 2))
             self._hyp_last = cur
 
     def zero_grad(self, set_to_none: bool = True):
