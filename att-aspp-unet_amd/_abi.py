@@ -89,6 +89,22 @@ _SIGS = {
     "aau_criterion": [P, P, P, P, P, I, I, I, I, F, F, F, P],
     "aau_seg_metrics": [P, P, P, P, I, I, I, F, P],
     "aau_seg_counts": [P, I, P, I, L, P, P],
+    "aau_resize_bilinear_f32": [P, I, I, P, I, I, I, P],
+    "aau_resize_bilinear_u8": [P, I, I, P, I, I, I, P],
+    "aau_gauss5_f32": [P, P, I, I, I, P],
+    "aau_threshold_u8": [P, F, P, L, P],
+    "aau_cc_label": [P, P, I, I, I, I, P],
+    "aau_cc_keep_largest": [P, P, P, P, P, I, I, I, I, I, P],
+    "aau_fill_holes": [P, P, P, P, I, I, I, P],
+    "aau_morph": [P, P, I, I, I, I, I, P],
+    "aau_normalize_minmax_u8": [P, P, P, I, I, I, P],
+    "aau_clahe_u8": [P, P, P, I, I, I, F, I, P],
+    "aau_median3_u8": [P, P, I, I, I, P],
+    "aau_u8_to_f32": [P, P, F, L, P],
+    "aau_roi_origin": [P, P, P, I, I, I, I, P],
+    "aau_roi_crop": [P, P, P, I, I, I, I, P],
+    "aau_roi_paste_sigmoid": [P, P, P, I, I, I, I, P],
+    "aau_frame_areas": [P, F, P, I, I, I, P],
     "aau_loss_terms": [P, P, P, P, P, I, I, I, C.POINTER(C.c_float), P],
     "aau_grad_sqnorm": [P, L, F, P, P],
     "aau_adamw_step": [P, P, P, P, L, P, P, F, F, F, F, F, F, F, P],

@@ -20,6 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.jo
          "-Wno-unused-result", "-Wno-unused-value"]
 
 
+# per-file flags: the image kernels restate published algorithms operation by operation (separately rounded multiplies
+# and adds), so hipcc's default fused-multiply-add contraction is off for that file
+EXTRA_FLAGS = {"imgproc.hip": ["-ffp-contract=off"]}
+
+
 def _newer(src: str, dst: str) -> bool:
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -42,7 +47,7 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") 
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), *[f"-D{d}" for d in defines], "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 

@@ -75,6 +75,109 @@ def predict_prob_tta(model, x):
     return prob[0, 0].cpu().numpy()
 
 
+@torch.inference_mode()
+def predict_prob_tta_batch(model, x):
+    """``predict_prob_tta`` for a batch, result left on the device: fp32 [B, H, W] probabilities (pipeline:336-338 per
+    slice; eval-mode BatchNorm makes the batched forward equal to B single-slice forwards)."""
+    B, _, H, W = x.shape
+    x = x.float().contiguous()
+    xf = torch.empty_like(x)
+    ops.hflip_f32(x, xf, B, H, W)
+    l = model(x)
+    lf = model(xf)
+    prob = torch.empty_like(l)
+    ops.tta_merge(l, lf, prob, B, H, W)
+    return prob[:, 0]
+
+
+@torch.inference_mode()
+def predict_masks(model, slices_u8, thr=0.48, batch=8, size=IMG_SIZE):
+    """The per-slice body of ``predict`` (pipeline:449-457 / :492-498) for a stack of raw uint8 slices [N, H, W], GPU
+    resident end to end: normalize -> CLAHE -> median -> resize 512 -> ToFloat | forward + h-flip TTA | resize back ->
+    Gaussian 5x5 -> threshold -> refine_mask.  Returns uint8 masks [N, H, W] on the device."""
+    from . import imgproc
+    if isinstance(slices_u8, np.ndarray):
+        slices_u8 = torch.from_numpy(np.ascontiguousarray(slices_u8))
+    dev = next(model.parameters()).device
+    sl = slices_u8.to(dev)
+    if sl.dim() == 2:
+        sl = sl[None]
+    N, H, W = sl.shape
+    x = imgproc.preprocess_frames(sl, size)
+    out = torch.empty(N, H, W, dtype=torch.uint8, device=dev)
+    model.eval()
+    for i in range(0, N, batch):
+        prob = predict_prob_tta_batch(model, x[i:i + batch])
+        out[i:i + batch] = imgproc.postprocess_probability(prob, (H, W), thr)
+    return out
+
+
+def _read_gray(path):
+    """cv2.imread(path, IMREAD_GRAYSCALE) through PIL (cv2 is not installed here): identical for single-channel files."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("L"), dtype=np.uint8)
+
+
+@torch.inference_mode()
+def calibrate(args):
+    """pipeline:376-396: sweep 17 thresholds in [0.1, 0.9] over the validation PNGs and keep the one with the best mean
+    Dice.  The probability maps are computed ONCE on the GPU (the reference re-runs the network for every threshold)."""
+    import json
+    from . import evalseg, imgproc
+    device = torch.device("cuda")
+    model = AttentionASPPUNet(base_c=args.base_c).to(device)
+    model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
+    model.eval()
+    val_dir = Path(args.val_dir)
+    imgs = sorted((val_dir / "images").glob("*.png"))
+    thrs = np.linspace(0.1, 0.9, 17)
+    sums = np.zeros(len(thrs))
+    for p in imgs:
+        sl = torch.from_numpy(_read_gray(p)).to(device)
+        gt = torch.from_numpy((_read_gray(val_dir / "masks" / p.name) > 127).astype(np.uint8)).to(device)
+        x = imgproc.preprocess_frames(sl[None], IMG_SIZE)
+        prob = imgproc.gaussian_blur5(imgproc.resize_bilinear(predict_prob_tta_batch(model, x), tuple(sl.shape)))
+        for k, thr in enumerate(thrs):
+            na, nb, ni = evalseg.counts(imgproc.threshold(prob, float(thr)), gt)
+            sums[k] += 2 * ni / (na + nb + 1e-7)
+    best_thr = float(thrs[int(np.argmax(sums / max(len(imgs), 1)))])
+    Path(args.output_dir).mkdir(parents=True, exist_ok=True)
+    json.dump({"best_thr": best_thr}, open(Path(args.output_dir) / "thr.json", "w"), indent=2)
+    print(f"Calibrated thr={best_thr:.3f}")
+    return best_thr
+
+
+@torch.inference_mode()
+def predict(args):
+    """pipeline:399-523 for PNG / JPG inputs: one mask PNG per slice, computed GPU-resident (``predict_masks``).  The
+    circumference measurement (cv2.findContours / fitEllipse, :350-374) and the MHA reader / writer (SimpleITK) are host
+    contour geometry and file formats outside the hot path: masks are written, AC is not."""
+    import json
+    from PIL import Image
+    set_seed()
+    device = torch.device("cuda")
+    thr = 0.48
+    cfg = Path("./checkpoints/thr.json")
+    if cfg.exists():
+        try:
+            thr = float(json.load(open(cfg))["best_thr"])
+        except Exception:
+            pass
+    model = AttentionASPPUNet(base_c=args.base_c).to(device)
+    model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
+    model.eval()
+    od = Path(args.out_dir)
+    od.mkdir(exist_ok=True, parents=True)
+    done = []
+    for p in sorted(Path(args.input_dir).iterdir()):
+        if p.suffix.lower() not in {".png", ".jpg", ".jpeg"}:
+            continue
+        mask = predict_masks(model, _read_gray(p), thr)[0]
+        Image.fromarray((mask * 255).cpu().numpy()).save(od / f"{p.stem}_mask.png")
+        done.append(p.stem)
+    return done
+
+
 class GraphedForward:
     """Eval-mode forward of a fixed input shape captured once as a hipGraph and replayed (inference is
     launch-latency bound at batch 1; the recorded plan has no host synchronisation, so it captures as is)."""

@@ -373,6 +373,49 @@ int aau_tta_merge(const float* l, const float* l_flipped, float* prob, int N, in
 int aau_window_blend(const float* win_logits, float* out, int H, int W, int win, int stride, int ny, int nx,
                      float sigma, void* stream);
 
+/* ---- GPU-resident inference tail and input pipeline ------------ */
+/* Batches of N frames, [N][H][W] row-major; uint8 masks hold 0 / 1.  Restated from the published algorithms   */
+/* of OpenCV / scikit-image / SciPy that the reference calls (cv2 and skimage are not importable in the build  */
+/* container, so those outputs are "parity unpinned"; the checker is oracle/imgproc_ref.py).                   */
+/* cv2.resize(INTER_LINEAR): fp32 (pipeline:455 resize-back of the probability map) / uint8 (11-bit fixed point, */
+/* albumentations Resize, pipeline:147,451)                                                                    */
+int aau_resize_bilinear_f32(const float* src, int Hs, int Ws, float* dst, int Hd, int Wd, int N, void* stream);
+int aau_resize_bilinear_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd, int N, void* stream);
+/* cv2.GaussianBlur(x, (5,5), 0): [1 4 6 4 1]/16 separable, BORDER_REFLECT_101 (pipeline:456)                    */
+int aau_gauss5_f32(const float* src, float* dst, int N, int H, int W, void* stream);
+/* (prob > thr).astype(uint8) (pipeline:457)                                                                   */
+int aau_threshold_u8(const float* src, float thr, uint8_t* dst, int64_t n, void* stream);
+/* connected components (skimage.measure.label / scipy.ndimage.label): labels[i] = smallest linear index of the  */
+/* pixel's component, -1 for background; conn8 = 8-connectivity                                                */
+int aau_cc_label(const uint8_t* mask, int32_t* labels, int N, int H, int W, int conn8, void* stream);
+/* refine_mask :341-345 / model_attention_aspp.py:76-80: out = the largest component if it has >= min_area        */
+/* pixels (the earliest in raster order on ties), else zeros.  Workspaces: labels, sizes int32 [N*H*W], best u64 [N] */
+int aau_cc_keep_largest(const uint8_t* mask, uint8_t* out, int32_t* labels_ws, int32_t* sizes_ws, uint64_t* best_ws,
+                        int N, int H, int W, int conn8, int min_area, void* stream);
+/* scipy.ndimage.binary_fill_holes (pipeline:348).  Workspaces int32 [N*H*W] each                                 */
+int aau_fill_holes(const uint8_t* mask, uint8_t* out, int32_t* labels_ws, int32_t* flag_ws, int N, int H, int W,
+                   void* stream);
+/* binary dilation (erode = 0) / erosion (erode = 1), pixels outside the frame ignored: shape 7 = cv2 7x7 ellipse */
+/* (MORPH_CLOSE of pipeline:347 = dilate then erode), shape 3 = full 3x3 (model_attention_aspp.py:75)             */
+int aau_morph(const uint8_t* src, uint8_t* dst, int N, int H, int W, int shape, int erode, void* stream);
+/* cv2.normalize(x, None, 0, 255, NORM_MINMAX) per frame (pipeline:449); mm_ws int32 [2N]                         */
+int aau_normalize_minmax_u8(const uint8_t* src, uint8_t* dst, int32_t* mm_ws, int N, int H, int W, void* stream);
+/* cv2.createCLAHE(clip_limit, (tiles, tiles)).apply (pipeline:450); lut_ws uint8 [N][tiles*tiles][256]           */
+int aau_clahe_u8(const uint8_t* src, uint8_t* dst, uint8_t* lut_ws, int N, int H, int W, float clip_limit, int tiles,
+                 void* stream);
+/* cv2.medianBlur(x, 3) (pipeline:450)                                                                           */
+int aau_median3_u8(const uint8_t* src, uint8_t* dst, int N, int H, int W, void* stream);
+/* ToFloat(max_value): dst = float(src) / max_value (pipeline:154,451)                                           */
+int aau_u8_to_f32(const uint8_t* src, float* dst, float max_value, int64_t n, void* stream);
+/* model_attention_aspp.py:20-31 crop_roi_224: origin[f] = (x0, y0) of the R x R window centred on the mean position */
+/* of the pixels brighter than 1.2 x the frame mean (frame centre if none), clamped to the frame; sums_ws fp64 [4N]  */
+int aau_roi_origin(const float* img, double* sums_ws, int32_t* origin, int N, int H, int W, int R, void* stream);
+int aau_roi_crop(const float* src, const int32_t* origin, float* dst, int N, int H, int W, int R, void* stream);
+/* :54-59: full-frame probability = sigmoid(logits) pasted at the window, 0 elsewhere                              */
+int aau_roi_paste_sigmoid(const float* logits, const int32_t* origin, float* full, int N, int H, int W, int R, void* stream);
+/* :66-69: areas[f] = #(prob > thr)                                                                                */
+int aau_frame_areas(const float* prob, float thr, int32_t* areas, int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

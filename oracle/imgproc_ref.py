@@ -1,0 +1,261 @@
+"""TEST INFRASTRUCTURE -- CPU restatement (numpy / SciPy) of the image processing around the network.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this package; the product path
+(att-aspp-unet_amd/imgproc.py -> csrc/imgproc.hip) never does.
+
+PARITY UNPINNED against the libraries themselves: the reference calls cv2 (resize, GaussianBlur, CLAHE, medianBlur,
+normalize, morphologyEx), skimage.measure.label and scipy.ndimage.binary_fill_holes
+(attention_aspp_unet_pipeline_stage.py:340-348,449-457; model_attention_aspp.py:14-31,66-85).  cv2 and skimage are not
+importable in the build container and the reference ships no fixtures for these steps, so the functions below restate
+the PUBLISHED algorithms (OpenCV 4.x imgproc sources: resize.cpp HResizeLinear / VResizeLinear, smooth.dispatch.cpp
+small Gaussian table, clahe.cpp, median_blur, morph; scikit-image label = 8-connected, raster-order numbering).  SciPy IS
+importable: ``scipy.ndimage.label`` / ``binary_fill_holes`` / ``median_filter`` are used directly where the reference
+uses SciPy or where SciPy computes the same documented result.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.ndimage as ndi
+
+F32 = np.float32
+
+
+# ---------------------------------------------------------------- cv2.resize(INTER_LINEAR)
+def _lin_coords(nd, ns):
+    scale = 1.0 / (np.float64(nd) / np.float64(ns))                  # resize.cpp: scale_x = 1. / inv_scale_x
+    f = ((np.arange(nd, dtype=np.float64) + 0.5) * scale - 0.5).astype(F32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(F32)).astype(F32)
+    lo = s < 0
+    f[lo] = 0; s[lo] = 0
+    hi = s >= ns - 1
+    f[hi] = 0; s[hi] = ns - 1
+    return s, np.minimum(s + 1, ns - 1), f
+
+
+def resize_linear_f32(img, size):
+    """pipeline:455 ``cv2.resize(prob, sl.shape[::-1])`` on fp32; ``size`` = (H, W)."""
+    img = np.asarray(img, F32)
+    Hd, Wd = size
+    Hs, Ws = img.shape
+    if (Hd, Wd) == (Hs, Ws):
+        return img.copy()
+    sx, sx1, fx = _lin_coords(Wd, Ws)
+    sy, sy1, fy = _lin_coords(Hd, Hs)
+    a0, a1 = (F32(1) - fx), fx
+    rows = (img[:, sx] * a0 + img[:, sx1] * a1).astype(F32)          # horizontal pass of every source row
+    b0, b1 = (F32(1) - fy)[:, None], fy[:, None]
+    return (rows[sy] * b0 + rows[sy1] * b1).astype(F32)
+
+
+def resize_linear_u8(img, size):
+    """albumentations Resize -> cv2.resize(uint8, INTER_LINEAR): 11-bit coefficients, 8-bit vertical pass."""
+    img = np.asarray(img, np.uint8)
+    Hd, Wd = size
+    Hs, Ws = img.shape
+    if (Hd, Wd) == (Hs, Ws):
+        return img.copy()
+    sx, sx1, fx = _lin_coords(Wd, Ws)
+    sy, sy1, fy = _lin_coords(Hd, Hs)
+    a0 = np.rint((F32(1) - fx) * F32(2048)).astype(np.int64)
+    a1 = np.rint(fx * F32(2048)).astype(np.int64)
+    b0 = np.rint((F32(1) - fy) * F32(2048)).astype(np.int64)[:, None]
+    b1 = np.rint(fy * F32(2048)).astype(np.int64)[:, None]
+    I = img.astype(np.int64)
+    rows = I[:, sx] * a0 + I[:, sx1] * a1
+    r0, r1 = rows[sy], rows[sy1]
+    return ((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+
+
+# ---------------------------------------------------------------- cv2.GaussianBlur(x, (5,5), 0)
+def _reflect101(idx, n):
+    idx = np.asarray(idx)
+    if n == 1:
+        return np.zeros_like(idx)
+    period = 2 * (n - 1)
+    idx = np.mod(idx, period)
+    return np.where(idx >= n, period - idx, idx)
+
+
+def gaussian_blur5(img):
+    img = np.asarray(img, F32)
+    H, W = img.shape
+    k0, k1, k2 = F32(0.375), F32(0.25), F32(0.0625)
+    xs = [_reflect101(np.arange(W) + d, W) for d in (-2, -1, 0, 1, 2)]
+    row = (img[:, xs[2]] * k0).astype(F32)
+    row = (row + ((img[:, xs[1]] + img[:, xs[3]]).astype(F32) * k1).astype(F32)).astype(F32)
+    row = (row + ((img[:, xs[0]] + img[:, xs[4]]).astype(F32) * k2).astype(F32)).astype(F32)
+    ys = [_reflect101(np.arange(H) + d, H) for d in (-2, -1, 0, 1, 2)]
+    out = (row[ys[2]] * k0).astype(F32)
+    out = (out + ((row[ys[1]] + row[ys[3]]).astype(F32) * k1).astype(F32)).astype(F32)
+    out = (out + ((row[ys[0]] + row[ys[4]]).astype(F32) * k2).astype(F32)).astype(F32)
+    return out
+
+
+# ---------------------------------------------------------------- refine_mask (pipeline:340-348)
+ELLIPSE7 = np.array([[0, 0, 0, 1, 0, 0, 0],
+                     [0, 1, 1, 1, 1, 1, 0],
+                     [1, 1, 1, 1, 1, 1, 1],
+                     [1, 1, 1, 1, 1, 1, 1],
+                     [1, 1, 1, 1, 1, 1, 1],
+                     [0, 1, 1, 1, 1, 1, 0],
+                     [0, 0, 0, 1, 0, 0, 0]], np.uint8)     # cv2.getStructuringElement(MORPH_ELLIPSE, (7, 7))
+
+
+def _morph(m, se, erode):
+    """Binary dilation / erosion; pixels outside the frame do not take part (cv2's default morphology border)."""
+    H, W = m.shape
+    r = se.shape[0] // 2
+    out = np.ones((H, W), bool) if erode else np.zeros((H, W), bool)
+    mb = m.astype(bool)
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            if not se[dy + r, dx + r]:
+                continue
+            ys, ye = max(0, -dy), min(H, H - dy)
+            xs, xe = max(0, -dx), min(W, W - dx)
+            sh = np.zeros((H, W), bool)
+            valid = np.zeros((H, W), bool)
+            sh[ys:ye, xs:xe] = mb[ys + dy:ye + dy, xs + dx:xe + dx]
+            valid[ys:ye, xs:xe] = True
+            if erode:
+                out &= sh | ~valid
+            else:
+                out |= sh
+    return out.astype(np.uint8)
+
+
+def close_ellipse7(m):
+    return _morph(_morph(m, ELLIPSE7, False), ELLIPSE7, True)
+
+
+def largest_component(m, min_area=1):
+    """skimage.measure.label (8-connected, raster numbering) + bincount / argmax of pipeline:341-345."""
+    lab, n = ndi.label(m != 0, structure=np.ones((3, 3)))
+    if n == 0:
+        return np.zeros_like(m, np.uint8)
+    cnt = np.bincount(lab.ravel())
+    cnt[0] = 0
+    best = int(cnt.argmax())
+    if cnt[best] < min_area:
+        return np.zeros_like(m, np.uint8)
+    return (lab == best).astype(np.uint8)
+
+
+def refine_mask(m):
+    m = (np.asarray(m) != 0).astype(np.uint8)
+    if m.sum() == 0:
+        return m
+    min_area = max(20, int(0.0015 * m.size))
+    big = largest_component(m, min_area)       # == filter by min_area, relabel, keep the largest (:343-345)
+    if big.sum() == 0:
+        return big
+    return ndi.binary_fill_holes(close_ellipse7(big)).astype(np.uint8)
+
+
+def postprocess_probability(prob512, out_hw, thr):
+    """pipeline:455-457."""
+    p = gaussian_blur5(resize_linear_f32(prob512, out_hw))
+    return refine_mask((p > F32(thr)).astype(np.uint8))
+
+
+# ---------------------------------------------------------------- input pipeline (pipeline:449-451)
+def normalize_minmax(u8):
+    u8 = np.asarray(u8, np.uint8)
+    lo, hi = int(u8.min()), int(u8.max())
+    if hi == lo:
+        return np.zeros_like(u8)
+    scale = 255.0 / (hi - lo)
+    return np.clip(np.rint(u8.astype(np.float64) * scale - lo * scale), 0, 255).astype(np.uint8)
+
+
+def clahe(u8, clip_limit=1.0, tiles=8):
+    """OpenCV clahe.cpp for 8-bit images."""
+    u8 = np.asarray(u8, np.uint8)
+    H, W = u8.shape
+    Hp = H + (tiles - H % tiles) % tiles
+    Wp = W + (tiles - W % tiles) % tiles
+    ext = u8[_reflect101(np.arange(Hp), H)][:, _reflect101(np.arange(Wp), W)] if (Hp, Wp) != (H, W) else u8
+    th, tw = Hp // tiles, Wp // tiles
+    area = th * tw
+    climit = 0
+    if clip_limit > 0:
+        climit = max(int(F32(clip_limit) * F32(area) / F32(256)), 1)
+    scale = F32(255.0) / F32(area)
+    luts = np.zeros((tiles, tiles, 256), np.uint8)
+    for ty in range(tiles):
+        for tx in range(tiles):
+            hist = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if climit > 0:
+                clipped = int(np.maximum(hist - climit, 0).sum())
+                hist = np.minimum(hist, climit)
+                batch = clipped // 256
+                residual = clipped - batch * 256
+                hist += batch
+                if residual:
+                    step = max(256 // residual, 1)
+                    i = 0
+                    while i < 256 and residual > 0:
+                        hist[i] += 1
+                        i += step
+                        residual -= 1
+            cdf = np.cumsum(hist).astype(F32)
+            luts[ty, tx] = np.clip(np.rint(cdf * scale), 0, 255).astype(np.uint8)
+    ys, xs = np.arange(H, dtype=F32), np.arange(W, dtype=F32)
+    tyf = ys * (F32(1) / F32(th)) - F32(0.5)
+    txf = xs * (F32(1) / F32(tw)) - F32(0.5)
+    ty1, tx1 = np.floor(tyf).astype(int), np.floor(txf).astype(int)
+    ya, xa = (tyf - ty1).astype(F32), (txf - tx1).astype(F32)
+    ty2, tx2 = np.minimum(ty1 + 1, tiles - 1), np.minimum(tx1 + 1, tiles - 1)
+    ty1, tx1 = np.maximum(ty1, 0), np.maximum(tx1, 0)
+    v = u8.astype(int)
+    l11 = luts[ty1[:, None], tx1[None, :], v].astype(F32)
+    l12 = luts[ty1[:, None], tx2[None, :], v].astype(F32)
+    l21 = luts[ty2[:, None], tx1[None, :], v].astype(F32)
+    l22 = luts[ty2[:, None], tx2[None, :], v].astype(F32)
+    xa_, xa1_ = xa[None, :], (F32(1) - xa)[None, :]
+    ya_, ya1_ = ya[:, None], (F32(1) - ya)[:, None]
+    res = ((l11 * xa1_).astype(F32) + (l12 * xa_).astype(F32)).astype(F32) * ya1_ + \
+          ((l21 * xa1_).astype(F32) + (l22 * xa_).astype(F32)).astype(F32) * ya_
+    return np.clip(np.rint(res.astype(F32)), 0, 255).astype(np.uint8)
+
+
+def median3(u8):
+    """cv2.medianBlur(x, 3): BORDER_REPLICATE."""
+    return ndi.median_filter(np.asarray(u8, np.uint8), size=3, mode="nearest")
+
+
+def preprocess_frame(u8, size=512):
+    """pipeline:449-451 -> fp32 [size, size] in [0, 1]."""
+    e = median3(clahe(normalize_minmax(u8)))
+    return resize_linear_u8(e, (size, size)).astype(F32) / F32(255)
+
+
+# ---------------------------------------------------------------- GC wrapper (model_attention_aspp.py)
+def crop_roi(img, R=224):
+    """:20-31 -> (patch, (x0, y0))."""
+    img = np.asarray(img, F32)
+    h, w = img.shape
+    thr = img.mean() * 1.2
+    ys, xs = np.where(img > thr)
+    cx, cy = (w // 2, h // 2) if len(xs) == 0 else (int(xs.mean()), int(ys.mean()))
+    x0, y0 = max(0, cx - R // 2), max(0, cy - R // 2)
+    x0, y0 = min(x0, w - R), min(y0, h - R)
+    return img[y0:y0 + R, x0:x0 + R], (x0, y0)
+
+
+def gc_postprocess(prob):
+    """:66-85."""
+    bin_ = (np.asarray(prob) > 0.05).astype(np.uint8)
+    frame_idx = int(bin_.sum((1, 2)).argmax())
+    if bin_[frame_idx].sum() == 0:
+        return np.zeros_like(bin_, np.uint8)
+    st = np.ones((3, 3), np.uint8)
+    frame = ndi.binary_dilation(bin_[frame_idx], structure=st, iterations=1)
+    labeled, n = ndi.label(frame, structure=st)
+    if n:
+        sizes = ndi.sum(frame, labeled, index=range(1, n + 1))
+        frame = (labeled == (np.argmax(sizes) + 1)).astype(np.uint8)
+    mask = np.zeros_like(bin_, np.uint8)
+    mask[frame_idx] = frame
+    return mask
