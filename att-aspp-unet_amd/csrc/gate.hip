@@ -403,3 +403,124 @@ extern "C" int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_b
                        redx, dzg, dzx, dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi_rep, dwpsi, M, F);
     return check_launch("aau_gate_bwd3");
 }
+
+// =====================================================================================================================
+// Residual attention gate of the ablation variant (test_ablation.py:128-143): no BatchNorm, bias on psi,
+//   a = sigmoid(psi_w . relu(Wg g + Wx x) + psi_b),   out = x * a + x
+// One wave per pixel (lanes own 8-channel groups, wave reductions by shuffles): Fint is max(8, C/4), so a pixel is at
+// most 48 lanes of x and 12 lanes of the gate sum.  HBM-bound; the two 1x1 GEMMs stay on the MFMA conv kernels.
+// =====================================================================================================================
+namespace aau {
+
+__global__ __launch_bounds__(256) void gate2_fwd_kernel(const unsigned short* zg, const unsigned short* zx, const float* wpsi,
+                                                        const float* bpsi, const unsigned short* x, int xp, float* alpha,
+                                                        unsigned short* out, int op, int64_t M, int F, int C) {
+    const int lane = threadIdx.x & 63;
+    const int FG = F >> 3, CG = C >> 3;
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = lane < FG ? wpsi[lane * 8 + j] : 0.f;
+    const float b = bpsi[0];
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t m = wave0; m < M; m += nw) {
+        float part = 0.f;
+        if (lane < FG) {
+            float g[8], h[8];
+            unpack8(*(const u32x4*)(zg + m * F + lane * 8), g);
+            unpack8(*(const u32x4*)(zx + m * F + lane * 8), h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += fmaxf(g[j] + h[j], 0.f) * w[j];
+        }
+        const float a = 1.f / (1.f + expf(-(wave_sum(part) + b)));
+        if (lane == 0) alpha[m] = a;
+        for (int cg = lane; cg < CG; cg += 64) {
+            float f[8];
+            unpack8(*(const u32x4*)(x + m * xp + cg * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = f[j] * a + f[j];
+            *(u32x4*)(out + m * op + cg * 8) = pack8(f);
+        }
+    }
+}
+
+// dx = dout * (1 + a) (written); dpre = <dout, x> * a (1 - a); ds[f] = dpre * w[f] * [s_f > 0] (written, bf16);
+// rep[block % R][f] += dpre * s_f, rep[..][F] += dpre  (folded into dwpsi / dbpsi by the launcher)
+__global__ __launch_bounds__(256) void gate2_bwd_kernel(const unsigned short* dout, int dop, const unsigned short* x, int xp,
+                                                        const float* alpha, const unsigned short* zg, const unsigned short* zx,
+                                                        const float* wpsi, unsigned short* dx, int dxp, unsigned short* ds,
+                                                        float* rep, int64_t M, int F, int C) {
+    const int lane = threadIdx.x & 63;
+    const int FG = F >> 3, CG = C >> 3;
+    float w[8], acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w[j] = lane < FG ? wpsi[lane * 8 + j] : 0.f; acc[j] = 0.f; }
+    float bsum = 0.f;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t m = wave0; m < M; m += nw) {
+        const float a = alpha[m];
+        float dot = 0.f;
+        for (int cg = lane; cg < CG; cg += 64) {
+            float g[8], xv[8];
+            unpack8(*(const u32x4*)(dout + m * dop + cg * 8), g);
+            unpack8(*(const u32x4*)(x + m * xp + cg * 8), xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dot += g[j] * xv[j]; g[j] = g[j] * a + g[j]; }
+            *(u32x4*)(dx + m * dxp + cg * 8) = pack8(g);
+        }
+        const float dpre = wave_sum(dot) * a * (1.f - a);
+        if (lane == 0) bsum += dpre;
+        if (lane < FG) {
+            float g[8], h[8], o[8];
+            unpack8(*(const u32x4*)(zg + m * F + lane * 8), g);
+            unpack8(*(const u32x4*)(zx + m * F + lane * 8), h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float s = g[j] + h[j];
+                o[j] = s > 0.f ? dpre * w[j] : 0.f;
+                acc[j] += dpre * fmaxf(s, 0.f);
+            }
+            *(u32x4*)(ds + m * F + lane * 8) = pack8(o);
+        }
+    }
+    float* r = rep + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * (F + 8);
+    if (lane < FG)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(r + lane * 8 + j, acc[j]);
+    if (lane == 0) atomicAdd(r + F, bsum);
+}
+
+}  // namespace aau
+
+extern "C" int aau_gate2_fwd(const aau_bf16* zg, const aau_bf16* zx, const float* wpsi, const float* bpsi, const aau_bf16* x,
+                             int x_pitch, float* alpha, aau_bf16* out, int out_pitch, int64_t M, int F, int C, void* stream) {
+    using namespace aau;
+    AAU_REQUIRE(zg && zx && wpsi && bpsi && x && alpha && out && M > 0, "aau_gate2_fwd: bad args");
+    AAU_REQUIRE(F > 0 && F % 8 == 0 && F <= 512 && C > 0 && C % 8 == 0, "aau_gate2_fwd: F=%d (<= 512) and C=%d must be multiples of 8", F, C);
+    AAU_REQUIRE(x_pitch % 8 == 0 && out_pitch % 8 == 0, "aau_gate2_fwd: pitch");
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    int64_t blocks = (M + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gate2_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, zg, zx, wpsi, bpsi, x, x_pitch,
+                       alpha, out, out_pitch, M, F, C);
+    return check_launch("aau_gate2_fwd");
+}
+
+extern "C" int aau_gate2_bwd(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x_pitch, const float* alpha,
+                             const aau_bf16* zg, const aau_bf16* zx, const float* wpsi, aau_bf16* dx, int dx_pitch, aau_bf16* ds,
+                             float* rep_ws, float* dwpsi, float* dbpsi, int64_t M, int F, int C, void* stream) {
+    using namespace aau;
+    AAU_REQUIRE(dout && x && alpha && zg && zx && wpsi && dx && ds && rep_ws && dwpsi && dbpsi && M > 0, "aau_gate2_bwd: bad args");
+    AAU_REQUIRE(F > 0 && F % 8 == 0 && F <= 512 && C > 0 && C % 8 == 0, "aau_gate2_bwd: F=%d (<= 512) and C=%d must be multiples of 8", F, C);
+    AAU_REQUIRE(dout_pitch % 8 == 0 && x_pitch % 8 == 0 && dx_pitch % 8 == 0, "aau_gate2_bwd: pitch");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(2, 0, s);
+    zero_f32(rep_ws, (int64_t)AAU_STAT_REPLICAS * (F + 8), s);
+    int64_t blocks = (M + 63) / 64;           // 16 pixels per wave: the per-workgroup replica atomics stay a small tail
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gate2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dout, dout_pitch, x, x_pitch, alpha, zg, zx,
+                       wpsi, dx, dx_pitch, ds, rep_ws, M, F, C);
+    if (int rc = check_launch("aau_gate2_bwd")) return rc;
+    if (int rc = aau_fold_replicas(rep_ws, F + 8, dwpsi, F, stream)) return rc;      // dwpsi[f] += sum of the replicas
+    return aau_fold_replicas(rep_ws + F, F + 8, dbpsi, 1, stream);
+}

@@ -332,7 +332,7 @@ class Plan:
         self.fwd_gen, self.bwd_gen = 0, -1   # training forwards run / generation whose backward has run (model._NetFn)
         # dropout seed in device memory, advanced on the stream once per training forward (graph-capturable)
         self.drop_seed = torch.tensor([eng.next_seed() >> 1], dtype=torch.int64, device=eng.store.device)
-        self.drop_p = float(eng.model.bridge.project[3].p) if train else 0.0
+        self.drop_p = eng.dropout_p() if train else 0.0
         st = eng.store
         nbn = st.bn_channels + 8
         self.stats_arena = _Arena(STAT_REPLICAS * 2 * nbn, self.dev)
@@ -341,6 +341,7 @@ class Plan:
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
         self.logits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
         self.dlogits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev) if train else None
+        self.psis = {}         # decoder level -> (alpha fp32 [M], h, w) of the residual gates (ablation variant)
         self.bwd_blocks = []   # per forward block: list of (name, args) recorded later in reverse
         self.bucket_hooks = {}  # block index -> callback fired after that block's backward
         self._build()
@@ -487,9 +488,13 @@ class Plan:
         f.add("aau_pack_weights", st.flat, st.packed, st.pack_table, st.pack_n, st.pack_blocks)
 
         # ---------------- encoder ----------------
-        cat1 = self.new(Ms[0], 2 * c)               # [x1 | up(d2)] for u1 (no gate): x1 is produced in place
-        skips = [cat1, self.new(Ms[1], Cs[1]), self.new(Ms[2], Cs[2]), self.new(Ms[3], Cs[3])]
-        skip_p = [2 * c, Cs[1], Cs[2], Cs[3]]
+        # an up-block WITHOUT a gate concatenates the encoder output as is: the encoder then writes its output straight
+        # into the lower half of that block's concat buffer (u1 always; u2..u4 of the ablation variant without attention)
+        gate_kinds = [eng.gate_kind(f"u{lv + 1}") for lv in range(4)]
+        cats = [self.new(Ms[lv], 2 * Cs[lv]) for lv in range(4)]
+        cat1 = cats[0]
+        skips = [cats[lv] if gate_kinds[lv] is None else self.new(Ms[lv], Cs[lv]) for lv in range(4)]
+        skip_p = [2 * Cs[lv] if gate_kinds[lv] is None else Cs[lv] for lv in range(4)]
         pools = [self.new(Ms[i + 1], Cs[i]) for i in range(4)]
         enc = []  # (rec0, rec1) per level
         # d1.0: direct kernel on the fp32 frame
@@ -525,26 +530,30 @@ class Plan:
             ra = self.cbr_fwd(f"d{lv + 1}.0.block.0", f"d{lv + 1}.0.block.1", pools[lv - 1], Cs[lv - 1], B, h, w_,
                               ya, Cs[lv])
             rb = self.cbr_fwd(f"d{lv + 1}.1.block.0", f"d{lv + 1}.1.block.1", ya, Cs[lv], B, h, w_, skips[lv],
-                              Cs[lv], pool=pools[lv])
+                              skip_p[lv], pool=pools[lv])
             enc.append((ra, rb))
 
-        # ---------------- bridge: ASPP ----------------
+        # ---------------- bridge: ASPP (pipeline:67-83) or ConvBNReLU + Dropout (ablation:194-197) ----------------
         h5, w5, M5 = Hs[4], Ws[4], Ms[4]
         Cb = Cs[4]
-        nbr = len(model.bridge.blocks)
-        ncat = (nbr + 1) * Cb
-        cat5 = self.new(M5, ncat)
         p4 = pools[3]
-        br = [self.cbr_fwd(f"bridge.blocks.{i}.0", f"bridge.blocks.{i}.1", p4, Cs[3], B, h5, w5,
-                           cat5[:, i * Cb:], ncat) for i in range(nbr)]
-        pooled = self.new(B, Cs[3])
-        gap_ws = self.new(B, max(Cs[3], Cb), dtype=F32)
-        f.label = "bridge.pool"
-        f.add("aau_gap_fwd", p4, Cs[3], pooled, gap_ws, B, h5 * w5, Cs[3])
-        rpool = self.cbr_fwd("bridge.pool.1", "bridge.pool.2", pooled, Cs[3], B, 1, 1, cat5[:, nbr * Cb:], ncat,
-                             bcast_hw=h5 * w5)
         bout = self.new(M5, Cb)
-        rproj = self.cbr_fwd("bridge.project.0", "bridge.project.1", cat5, ncat, B, h5, w5, bout, Cb, drop=True)
+        aspp = hasattr(model.bridge, "blocks")
+        if aspp:
+            nbr = len(model.bridge.blocks)
+            ncat = (nbr + 1) * Cb
+            cat5 = self.new(M5, ncat)
+            br = [self.cbr_fwd(f"bridge.blocks.{i}.0", f"bridge.blocks.{i}.1", p4, Cs[3], B, h5, w5,
+                               cat5[:, i * Cb:], ncat) for i in range(nbr)]
+            pooled = self.new(B, Cs[3])
+            gap_ws = self.new(B, max(Cs[3], Cb), dtype=F32)
+            f.label = "bridge.pool"
+            f.add("aau_gap_fwd", p4, Cs[3], pooled, gap_ws, B, h5 * w5, Cs[3])
+            rpool = self.cbr_fwd("bridge.pool.1", "bridge.pool.2", pooled, Cs[3], B, 1, 1, cat5[:, nbr * Cb:], ncat,
+                                 bcast_hw=h5 * w5)
+            rproj = self.cbr_fwd("bridge.project.0", "bridge.project.1", cat5, ncat, B, h5, w5, bout, Cb, drop=True)
+        else:
+            rplain = self.cbr_fwd("bridge.0.block.0", "bridge.0.block.1", p4, Cs[3], B, h5, w5, bout, Cb, drop=True)
 
         # ---------------- decoder ----------------
         dec = []
@@ -555,12 +564,27 @@ class Plan:
             hi, wi = Hs[lv + 1], Ws[lv + 1]     # input grid of the up-conv
             ho, wo, Mo = Hs[lv], Ws[lv], Ms[lv]
             up = st.convs[f"{name}.up"]
-            cat = cat1 if lv == 0 else self.new(Mo, 2 * Co)
+            cat = cats[lv]
+            kind = gate_kinds[lv]
             dup = ops.conv_desc(B, hi, wi, g_c, g_c, hi, wi, 4 * Co, 2 * Co, Cpad=up.cpad_f, shuffle2x2=1)
             f.label = f"{name}.up"
             f.add("aau_conv_igemm", dup, g_in, up.pk_f, cat[:, Co:], up.bias, None, None, None)
             gate = None
-            if lv > 0:
+            if kind == "res":
+                wg, wx, psi = st.convs[f"{name}.att.Wg"], st.convs[f"{name}.att.Wx"], st.convs[f"{name}.att.psi.1"]
+                Fi = wg.O
+                zg, zx = self.new(Mo, Fi), self.new(Mo, Fi)
+                alpha = self.new(Mo, dtype=F32)
+                f.label = f"{name}.att"
+                dg = ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi, Cpad=wg.cpad_f)
+                dx = ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi, Cpad=wx.cpad_f)
+                f.add("aau_conv_igemm", dg, cat[:, Co:], wg.pk_f, zg, None, None, None, None)
+                f.add("aau_conv_igemm", dx, skips[lv], wx.pk_f, zx, None, None, None, None)
+                f.add("aau_gate2_fwd", zg, zx, psi.w, psi.bias, skips[lv], skip_p[lv], alpha, cat, 2 * Co, Mo, Fi, Co)
+                gate = dict(kind="res", wg=wg, wx=wx, psi=psi, zg=zg, zx=zx, alpha=alpha, Fi=Fi,
+                            rep=self.new(STAT_REPLICAS * (Fi + 8), dtype=F32) if tr else None)
+                self.psis[lv] = (alpha, ho, wo)
+            elif kind == "bn":
                 Fi = Co // 2
                 wg, wx = st.convs[f"{name}.att.Wg.0"], st.convs[f"{name}.att.Wx.0"]
                 bg, bx, b1 = st.bns[f"{name}.att.Wg.1"], st.bns[f"{name}.att.Wx.1"], st.bns[f"{name}.att.psi.1"]
@@ -588,7 +612,7 @@ class Plan:
                     self._bn_fold(b1, w1)
                 f.add("aau_gate_apply", skips[lv], skip_p[lv], psi_pre, w1["scale"], w1["shift"], alpha, cat, 2 * Co,
                       Mo, Co)
-                gate = dict(wg=wg, wx=wx, psi=psi, bg=bg, bx=bx, b1=b1, wgb=wgb, wxb=wxb, w1=w1, zg=zg, zx=zx,
+                gate = dict(kind="bn", wg=wg, wx=wx, psi=psi, bg=bg, bx=bx, b1=b1, wgb=wgb, wxb=wxb, w1=w1, zg=zg, zx=zx,
                             psi_pre=psi_pre, alpha=alpha, Fi=Fi,
                             wrep=self.red_arena.take(STAT_REPLICAS * Fi) if tr else None)
             ya = self.new(Mo, Co)
@@ -617,8 +641,9 @@ class Plan:
         if not fused_head:
             dy = self.new(Ms[0], c)
             b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, rep_ws, Ms[0], c)
-        dskip = [None, self.new(Ms[1], Cs[1]), self.new(Ms[2], Cs[2]), self.new(Ms[3], Cs[3])]
-        dcat1 = None
+        # gradient of the encoder outputs: its own buffer behind a gate, the lower half of dcat otherwise
+        dskip = [None if gate_kinds[lv] is None else self.new(Ms[lv], Cs[lv]) for lv in range(4)]
+        dskip_p = [2 * Cs[lv] if gate_kinds[lv] is None else Cs[lv] for lv in range(4)]
         for blk in reversed(dec):            # u1, u2, u3, u4
             lv, Co, Mo, ho, wo, hi, wi = blk["lv"], blk["Co"], blk["Mo"], blk["ho"], blk["wo"], blk["hi"], blk["wi"]
             dya = self.new(Mo, Co)
@@ -627,10 +652,24 @@ class Plan:
             # channel sums of dcat (fp32, from the data-gradient epilogue) -> ConvTranspose2d bias gradient below
             sA = None if eng.no_fuse_colsum else self.red_arena.take(STAT_REPLICAS * 2 * 2 * Co)
             self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=2 * Co, din_stats=sA)
-            if lv == 0:
-                dcat1 = dcat
+            if gate_kinds[lv] is None:
+                dskip[lv] = dcat
             cat, gt, up = blk["cat"], blk["gate"], blk["up"]
-            if gt is not None:
+            if gt is not None and gt["kind"] == "res":
+                b.label = f"{blk['name']}.att"
+                Fi = gt["Fi"]
+                wg, wx, psi = gt["wg"], gt["wx"], gt["psi"]
+                ds = self.new(Mo, Fi)
+                b.add("aau_gate2_bwd", dcat, 2 * Co, skips[lv], skip_p[lv], gt["alpha"], gt["zg"], gt["zx"], psi.w,
+                      dskip[lv], Co, ds, gt["rep"], psi.dw, psi.dbias, Mo, Fi, Co)
+                b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], ds, wg.dw)
+                b.add_wgrad(ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], ds, wx.dw)
+                sB = None if sA is None else self.red_arena.take(STAT_REPLICAS * 2 * Co)
+                b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, 2 * Co, Cpad=wg.cpad_d,
+                                                      accumulate=1), ds, wg.pk_d, dcat[:, Co:], None, None, None, sB)
+                b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, Co, Cpad=wx.cpad_d,
+                                                      accumulate=1), ds, wx.pk_d, dskip[lv], None, None, None, None)
+            elif gt is not None:
                 b.label = f"{blk['name']}.att"
                 Fi = gt["Fi"]
                 w1, wgb, wxb = gt["w1"], gt["wgb"], gt["wxb"]
@@ -678,44 +717,44 @@ class Plan:
             dy = dg_in
             mark(blk["name"])
         # bridge
-        dcat5 = self.new(M5, ncat)
-        # the weight gradients of the projection and of the spatial branches go into ONE grouped launch
-        # (aau_conv_wgrad_group) once every branch's dz exists; their data gradients run as before
-        wg = [] if not eng.no_wgrad_group else None
-        self.cbr_bwd(rproj, dy, Cb, din=dcat5, dinp=ncat, defer_wgrad=wg)
         dp4 = self.new(M5, Cs[3])
-        for i, r in enumerate(br):
-            self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0, defer_wgrad=wg)
-        if wg:
-            descs = [w_[0] for w_ in wg]
-            b.label = "bridge(grouped)"
-            if len(wg) <= 8 and ops.conv_wgrad_group_ok(descs):
-                pack = ops.wgrad_group_args(descs, [w_[1] for w_ in wg], [w_[2] for w_ in wg], [w_[3] for w_ in wg])
-                b.keep.extend([w_[k] for w_ in wg for k in (1, 2, 3)])
-                b.keep.append(pack)
-                b.add("aau_conv_wgrad_group", *pack)
-            else:
-                for dwd, src, dz_, dw_, lab in wg:
-                    b.label = lab
-                    b.add_wgrad(dwd, src, dz_, dw_)
-        dpb = self.new(B, Cb)
-        b.label = "bridge.pool"
-        b.add("aau_spatial_sum", dcat5[:, nbr * Cb:], ncat, dpb, gap_ws, B, h5 * w5, Cb)
-        dpooled = self.new(B, Cs[3])
-        rpool_b = dict(rpool)
-        rpool_b["bcast_hw"] = 0
-        self.cbr_bwd(rpool_b, dpb, Cb, din=dpooled, dinp=Cs[3])
-        b.label = "bridge.pool"
-        b.add("aau_gap_bwd", dpooled, dp4, Cs[3], B, h5 * w5, Cs[3])
+        if aspp:
+            dcat5 = self.new(M5, ncat)
+            # the weight gradients of the projection and of the spatial branches go into ONE grouped launch
+            # (aau_conv_wgrad_group) once every branch's dz exists; their data gradients run as before
+            wg = [] if not eng.no_wgrad_group else None
+            self.cbr_bwd(rproj, dy, Cb, din=dcat5, dinp=ncat, defer_wgrad=wg)
+            for i, r in enumerate(br):
+                self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0, defer_wgrad=wg)
+            if wg:
+                descs = [w_[0] for w_ in wg]
+                b.label = "bridge(grouped)"
+                if len(wg) <= 8 and ops.conv_wgrad_group_ok(descs):
+                    pack = ops.wgrad_group_args(descs, [w_[1] for w_ in wg], [w_[2] for w_ in wg], [w_[3] for w_ in wg])
+                    b.keep.extend([w_[k] for w_ in wg for k in (1, 2, 3)])
+                    b.keep.append(pack)
+                    b.add("aau_conv_wgrad_group", *pack)
+                else:
+                    for dwd, src, dz_, dw_, lab in wg:
+                        b.label = lab
+                        b.add_wgrad(dwd, src, dz_, dw_)
+            dpb = self.new(B, Cb)
+            b.label = "bridge.pool"
+            b.add("aau_spatial_sum", dcat5[:, nbr * Cb:], ncat, dpb, gap_ws, B, h5 * w5, Cb)
+            dpooled = self.new(B, Cs[3])
+            rpool_b = dict(rpool)
+            rpool_b["bcast_hw"] = 0
+            self.cbr_bwd(rpool_b, dpb, Cb, din=dpooled, dinp=Cs[3])
+            b.label = "bridge.pool"
+            b.add("aau_gap_bwd", dpooled, dp4, Cs[3], B, h5 * w5, Cs[3])
+        else:
+            self.cbr_bwd(rplain, dy, Cb, din=dp4, dinp=Cs[3])
         mark("bridge")
         # encoder
         dpool = dp4
         for lv in (3, 2, 1, 0):
             ra, rb = enc[lv]
-            if lv == 0:
-                dsk, dskp = dcat1, 2 * c
-            else:
-                dsk, dskp = dskip[lv], Cs[lv]
+            dsk, dskp = dskip[lv], dskip_p[lv]
             dya = self.new(Ms[lv], Cs[lv])
             self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv], feeds=ra)
             if lv > 0:
@@ -733,6 +772,18 @@ class Plan:
             self.bwd.callback(cb)
         elif name == "d1":
             self.bwd.join()          # end of backward: everything is back on the main stream
+
+    def psi_outputs(self):
+        """[psi3, psi2] of test_ablation.py:218: the attention maps of u4 and u3 ([B,1,h,w]); a block without a gate
+        gives the DummyAttention placeholder zeros(1,1,1,1)."""
+        out = []
+        for lv in (3, 2):
+            if lv in self.psis:
+                a, h, w = self.psis[lv]
+                out.append(a.view(self.B, 1, h, w).clone())
+            else:
+                out.append(torch.zeros(1, 1, 1, 1, device=self.dev))
+        return out
 
     # ---- execution ----
     def run_forward(self, x: torch.Tensor):
@@ -782,6 +833,20 @@ class Engine:
         # (elementwise -0.41 ms, conv +0.43 ms per step: the epilogue's extra z read is not hidden), so opt-in
         self.no_fuse_bnred = os.environ.get("AAU_FUSE_BNRED", "0") != "1"
 
+    def dropout_p(self) -> float:
+        """p of the bridge's Dropout: ASPP.project[3] (pipeline:78) or Sequential(ConvBNReLU, Dropout)[1] (ablation:196)."""
+        for m in self.model.bridge.modules():
+            if isinstance(m, nn.Dropout):
+                return float(m.p)
+        return 0.0
+
+    def gate_kind(self, name: str):
+        """'bn': pipeline:85-92 (BatchNorm gate, x*a); 'res': ablation:128-143 (no BN, x*a + x); None: DummyAttention."""
+        att = getattr(self.model, name).att
+        if hasattr(att, "Wg"):
+            return "bn" if isinstance(att.Wg, nn.Sequential) else "res"
+        return None
+
     def next_seed(self) -> int:
         """Seeds of the Dropout masks follow ``torch.manual_seed`` (pipeline:33-52 ``set_seed``): the chain starts from
         torch's seed mixed with the data-parallel rank, so two seeds -- or two ranks -- give different
@@ -817,7 +882,7 @@ class Engine:
         return self.store
 
     def plan(self, B, H, W, train) -> Plan:
-        key = (B, H, W, bool(train), float(self.model.bridge.project[3].p) if train else 0.0,
+        key = (B, H, W, bool(train), self.dropout_p() if train else 0.0,
                self.bucket_cb is not None, self.overlap_wgrad)
         p = self.plans.get(key)
         if p is None:

@@ -312,6 +312,18 @@ int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float* ws, int64_
 /* channel sum of the gradient that the preceding data-gradient convs produced.                 */
 int aau_fold_replicas(const float* ws, int stride, float* out, int n, void* stream);
 
+/* Residual gate of the ablation variant (test_ablation.py:128-143; no BatchNorm, bias on psi):     */
+/*   alpha[m] = sigmoid(sum_f wpsi[f]*relu(zg[m,f]+zx[m,f]) + bpsi);  out[m,c] = x[m,c]*alpha[m] + x[m,c] */
+int aau_gate2_fwd(const aau_bf16* zg, const aau_bf16* zx, const float* wpsi, const float* bpsi,
+                  const aau_bf16* x, int x_pitch, float* alpha, aau_bf16* out, int out_pitch, int64_t M,
+                  int F, int C, void* stream);
+/* backward: dx = dout*(1+alpha) (written); ds[m,f] = dpre*wpsi[f]*[s>0] with dpre = <dout,x>*alpha*(1-alpha)  */
+/* (the gradient of BOTH 1x1 outputs); dwpsi += sum dpre*relu(s), dbpsi += sum dpre; rep_ws fp32                */
+/* [AAU_STAT_REPLICAS][F+8]                                                                                   */
+int aau_gate2_bwd(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x_pitch, const float* alpha,
+                  const aau_bf16* zg, const aau_bf16* zx, const float* wpsi, aau_bf16* dx, int dx_pitch,
+                  aau_bf16* ds, float* rep_ws, float* dwpsi, float* dbpsi, int64_t M, int F, int C, void* stream);
+
 /* ---- criterion (pipeline:219-232 build_criterion with ComboLoss :187-189, DiceLoss        */
 /* :173-178, EdgeLoss :196-216) and metrics (:191-194 iou_score, :240 eval Dice) -------- */
 /* sums: fp32 [AAU_STAT_REPLICAS][B][8] workspace (zeroed by the call; [0] holds the per-   */
