@@ -81,6 +81,8 @@ _SIGS = {
     "aau_gate_bwd3": [P] * 19 + [L, I, P],
     "aau_gate2_fwd": [P, P, P, P, P, I, P, P, I, L, I, I, P],
     "aau_gate2_bwd": [P, I, P, I, P, P, P, P, P, I, P, P, P, P, L, I, I, P],
+    "aau_fold_stats": [P, I, I, I, I, P, P],
+    "aau_stats_to_f64": [P, I, P, P],
     "aau_outconv_fwd": [P, I, P, P, P, L, I, P],
     "aau_outconv_bwd": [P, I, P, P, P, I, P, P, P, L, I, P],
     "aau_colsum": [P, I, P, P, L, I, P],

@@ -70,7 +70,7 @@ def conv_bn(conv, bn, x, out=None, out_pitch=None, relu=True, training=True, bca
     wpk, cp = _pack_conv(conv.weight)
     M = B * H * W
     z = torch.empty(B, H, W, O, dtype=BF16, device=x.device)
-    stats = torch.zeros(ops.STAT_REPLICAS, 2, O, device=x.device) if training else None
+    stats = ops.stats_buffer(O, x.device) if training else None
     d = ops.conv_desc(B, H, W, Cin, ops.pitch_of(x), H, W, O, O, k, k, 1, dil * (k // 2), dil, cp)
     ops.conv_igemm(d, x, wpk, z, stats=stats)
     scale, shift = _bn_scale_shift(bn, stats, M, training)
@@ -122,7 +122,7 @@ def _gate(mod, gh, xh, out, out_pitch, training):
     def branch(seq, src):
         wpk, cp = _pack_conv(seq[0].weight)
         z = torch.empty(M, Fi, dtype=BF16, device=dev)
-        st = torch.zeros(ops.STAT_REPLICAS, 2, Fi, device=dev) if training else None
+        st = ops.stats_buffer(Fi, dev) if training else None
         d = ops.conv_desc(B, H, W, src.shape[-1], ops.pitch_of(src), H, W, Fi, Fi, Cpad=cp)
         ops.conv_igemm(d, src, wpk, z, stats=st)
         sc, sh = _bn_scale_shift(seq[1], st, M, training)
@@ -131,7 +131,7 @@ def _gate(mod, gh, xh, out, out_pitch, training):
     zg, sg, hg = branch(mod.Wg, gh)
     zx, sx, hx = branch(mod.Wx, xh)
     psi_pre = torch.empty(M, device=dev)
-    st1 = torch.zeros(ops.STAT_REPLICAS, 2, 1, device=dev) if training else None
+    st1 = ops.stats_buffer(1, dev) if training else None
     ops.gate_psi(zg, zx, sg, hg, sx, hx, mod.psi[0].weight.detach().reshape(-1).contiguous(), psi_pre, st1, M, Fi)
     sc1, sh1 = _bn_scale_shift(mod.psi[1], st1, M, training)
     ops.gate_apply(xh, ops.pitch_of(xh), psi_pre, sc1, sh1, None, out, out_pitch, M, C_)

@@ -45,19 +45,17 @@ __device__ __forceinline__ void ldf8(const float* p, float f[8]) {
 }
 
 // ------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* stats, const float* gamma, const float* beta,
+__global__ void bn_finalize_kernel(const long long* stats, const float* gamma, const float* beta,
                                    float* rmean, float* rvar, int64_t* nbt, float* scale, float* shift,
                                    float* smean, float* sinvstd, int C, float count, float eps, float mom) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
-        s1 += stats[(size_t)r * 2 * C + c];
-        s2 += stats[(size_t)r * 2 * C + C + c];
-    }
-    const float mean = s1 / count;
-    const float var = fmaxf(s2 / count - mean * mean, 0.f);
+    // exact integer fold of the fixed-point replicas (common.h); mean / variance formed in fp64, rounded once
+    const double s1 = stat_total(stats, C, 0, c), s2 = stat_total(stats, C, 1, c);
+    const double mean_d = s1 / (double)count;
+    const float mean = (float)mean_d;
+    const float var = fmaxf((float)(s2 / (double)count - mean_d * mean_d), 0.f);
     const float invstd = 1.0f / sqrtf(var + eps);
     const float sc = gamma[c] * invstd;
     scale[c] = sc;
@@ -499,14 +497,14 @@ using namespace aau;
 
 #define CHK_C(fn, C) AAU_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) <= 2048, fn ": C=%d must be a multiple of 8 in [8, 2048]", (int)(C))
 
-extern "C" int aau_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+extern "C" int aau_bn_finalize(const aau_stat* stats, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
                                float* save_mean, float* save_invstd, int C, int64_t count, float eps,
                                float momentum, void* stream) {
     AAU_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd, "aau_bn_finalize: null pointer");
     AAU_REQUIRE(C > 0 && count > 0, "aau_bn_finalize: C=%d count=%lld", C, (long long)count);
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, gamma,
                        beta, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C,
                        (float)count, eps, momentum);
     return check_launch("aau_bn_finalize");

@@ -96,6 +96,59 @@ __device__ __forceinline__ void conv1_taps(const float* img, int yy, int xx, int
         }
 }
 
+// ---- order-independent per-channel statistics -----------------------------------------------------------------------
+// BatchNorm batch statistics are sums over thousands of workgroups.  fp32 atomics make them depend on the arrival
+// order; through bf16 rounding and ReLU / max-pool routing that noise is amplified into visibly different logits and
+// gradients from one run to the next (round 1: gradient cosine 0.99 between identical steps).  Integer adds are
+// associative, so every partial sum is added as a TWO-LIMB FIXED-POINT number:
+//     value = hi * 2^-8 + lo * 2^-52       (hi, lo: int64, 64-bit atomic adds)
+// hi holds the partial rounded to a multiple of 2^-8 (|value| < 3.6e16), lo the remainder (|lo| <= 2^43 per add, so
+// 2^19 adds per slot cannot overflow); a partial is represented exactly down to 2^-52 absolute.  The result is the
+// same bit pattern for every arrival order.  A non-finite partial raises the buffer's poison word instead (the reader
+// then returns NaN, which keeps the "skip the step on inf / nan" behaviour of pipeline:322-324).
+// Layout of a statistics buffer for C channels: int64 [AAU_STAT_REPLICAS][2][C][2 limbs], then the poison word.
+#define AAU_STAT_WORDS(C) ((size_t)AAU_STAT_REPLICAS * 2 * (size_t)(C) * 2 + 2)   /* int64 words incl. poison + pad */
+
+__device__ __forceinline__ void stat_add(long long* base, int C, int replica, int which, int c, float v) {
+    unsigned long long* slot = (unsigned long long*)base + (((size_t)replica * 2 + which) * C + c) * 2;
+    if (!(fabsf(v) < 3.0e16f)) {          // inf, nan or beyond the fixed-point range
+        atomicOr((unsigned long long*)base + (size_t)AAU_STAT_REPLICAS * 2 * C * 2, 1ull);
+        return;
+    }
+    const double d = (double)v;
+    const double h = rint(d * 256.0);
+    const double r = d - h * (1.0 / 256.0);                              // exact
+    const long long hi = (long long)h, lo = (long long)rint(r * 4503599627370496.0);
+    if (hi) atomicAdd(slot, (unsigned long long)hi);
+    if (lo) atomicAdd(slot + 1, (unsigned long long)lo);
+}
+// sum over the replicas of statistic `which` of channel c (NaN if the buffer is poisoned)
+__device__ __forceinline__ double stat_total(const long long* base, int C, int which, int c) {
+    if (base[(size_t)AAU_STAT_REPLICAS * 2 * C * 2] != 0) return __longlong_as_double(0x7ff8000000000000ll);
+    long long hi = 0, lo = 0;
+    for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
+        const long long* s = base + (((size_t)r * 2 + which) * C + c) * 2;
+        hi += s[0];
+        lo += s[1];
+    }
+    return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 4503599627370496.0);
+}
+
+// Workgroup part of a conv epilogue's statistics: every wave has stored its per-channel row sums in ITS OWN block of
+// `sst` ([nwaves][2][BQ] floats, zero where a wave has no share); thread t < 2*BQ adds the blocks in wave order (a fixed
+// order, unlike LDS atomics) and publishes one fixed-point add per channel and workgroup.
+__device__ __forceinline__ void stats_publish(const float* sst, int nwaves, int BQ, int tid, int q0, int Cout,
+                                              long long* stats, int replica) {
+    if (tid < 2 * BQ) {
+        const int which = tid / BQ, ql = tid - which * BQ;
+        if (q0 + ql < Cout) {
+            float v = 0.f;
+            for (int w = 0; w < nwaves; ++w) v += sst[w * 2 * BQ + tid];
+            stat_add(stats, Cout, replica, which, q0 + ql, v);
+        }
+    }
+}
+
 // Flat index -> coordinates with 32-bit unsigned division (indices stay below 2^31; the int64 form of % and / costs
 // on the order of a hundred VALU instructions per pixel and showed up as 30-40 % of the pooled BN kernels).
 __device__ __forceinline__ void decode3(int64_t i, int W, int H, int& x, int& y, int& n) {

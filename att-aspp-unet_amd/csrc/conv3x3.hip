@@ -325,26 +325,35 @@ __global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
     if (want_stats) {
         // per-wave row sums (DPP), combined across the 4 waves in LDS (the tiles are dead now),
         // then ONE global atomic per channel and workgroup
-        float* sst = (float*)smem;                      // [2][BQ]
+        // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
+        // fixed-point add per channel and workgroup (common.h: stat_add)
+        float* sst = (float*)smem;                      // [NWAVE][2][BQ]
         __syncthreads();                                // every wave is done reading the LDS tiles
-        if (tid < 2 * BQ) sst[tid] = 0.f;
+        for (int i = tid; i < NWAVE * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
+        float* mine = sst + wave * 2 * BQ;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
                 if (fr == 0) {
-                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
-                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
                 }
             }
         }
         __syncthreads();
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-        if (tid < 2 * BQ) {
-            const int which = tid / BQ, ql = tid - which * BQ;
-            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
+            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+            if (tid < 2 * BQ) {
+                const int which = tid / BQ, ql = tid - which * BQ;
+                float v = 0.f;
+                for (int w = 0; w < NWAVE; ++w) v += sst[w * 2 * BQ + tid];
+                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
+            }
+        } else {
+            stats_publish(sst, NWAVE, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
         }
     }
 #ifdef ABL_STAMP
@@ -556,26 +565,35 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
         }
     }
     if (want_stats) {
-        float* sst = (float*)smem;
+        // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
+        // fixed-point add per channel and workgroup (common.h: stat_add)
+        float* sst = (float*)smem;                      // [4][2][BQ]
         __syncthreads();
-        if (tid < 2 * BQ) sst[tid] = 0.f;
+        for (int i = tid; i < 4 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
+        float* mine = sst + wave * 2 * BQ;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
                 if (fr == 0) {
-                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
-                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
                 }
             }
         }
         __syncthreads();
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-        if (tid < 2 * BQ) {
-            const int which = tid / BQ, ql = tid - which * BQ;
-            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
+            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+            if (tid < 2 * BQ) {
+                const int which = tid / BQ, ql = tid - which * BQ;
+                float v = 0.f;
+                for (int w = 0; w < 4; ++w) v += sst[w * 2 * BQ + tid];
+                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
+            }
+        } else {
+            stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
         }
     }
 }
@@ -798,26 +816,35 @@ __global__ __launch_bounds__(320) void conv3x3l_kernel(const C3Args a) {
         }
     }
     if (want_stats) {
-        float* sst = (float*)smem;
+        // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
+        // fixed-point add per channel and workgroup (common.h: stat_add)
+        float* sst = (float*)smem;                      // [5][2][BQ]
         __syncthreads();
-        if (tid < 2 * BQ) sst[tid] = 0.f;
+        for (int i = tid; i < 5 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
+        float* mine = sst + wave * 2 * BQ;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
                 if (fr == 0 && !loader) {
-                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
-                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
                 }
             }
         }
         __syncthreads();
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-        if (tid < 2 * BQ) {
-            const int which = tid / BQ, ql = tid - which * BQ;
-            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
+            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+            if (tid < 2 * BQ) {
+                const int which = tid / BQ, ql = tid - which * BQ;
+                float v = 0.f;
+                for (int w = 0; w < 5; ++w) v += sst[w * 2 * BQ + tid];
+                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
+            }
+        } else {
+            stats_publish(sst, 5, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
         }
     }
 }
@@ -999,27 +1026,36 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
         }
     }
     if (want_stats) {
-        float* sst = (float*)dsm;   // halo buffers are dead
+        // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
+        // fixed-point add per channel and workgroup (common.h: stat_add)
+        float* sst = (float*)dsm;                      // [NW][2][BQ]
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < 2 * BQ) sst[tid] = 0.f;
+        for (int i = tid; i < NW * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
+        float* mine = sst + wave * 2 * BQ;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
                 if (fr == 0) {
-                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
-                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
                 }
             }
         }
         __syncthreads();
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-        if (tid < 2 * BQ) {
-            const int which = tid / BQ, ql = tid - which * BQ;
-            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
+            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+            if (tid < 2 * BQ) {
+                const int which = tid / BQ, ql = tid - which * BQ;
+                float v = 0.f;
+                for (int w = 0; w < NW; ++w) v += sst[w * 2 * BQ + tid];
+                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
+            }
+        } else {
+            stats_publish(sst, NW, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
         }
     }
 }
@@ -1196,27 +1232,36 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
         }
     }
     if (want_stats) {
-        float* sst = (float*)dsm;   // halo buffers are dead
+        // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
+        // fixed-point add per channel and workgroup (common.h: stat_add)
+        float* sst = (float*)dsm;                      // [8][2][BQ]
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < 2 * BQ) sst[tid] = 0.f;
+        for (int i = tid; i < 8 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
+        float* mine = sst + wave8 * 2 * BQ;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
                 if (fr == 0) {
-                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
-                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
                 }
             }
         }
         __syncthreads();
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-        if (tid < 2 * BQ) {
-            const int which = tid / BQ, ql = tid - which * BQ;
-            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
+            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+            if (tid < 2 * BQ) {
+                const int which = tid / BQ, ql = tid - which * BQ;
+                float v = 0.f;
+                for (int w = 0; w < 8; ++w) v += sst[w * 2 * BQ + tid];
+                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
+            }
+        } else {
+            stats_publish(sst, 8, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
         }
     }
 }
@@ -1416,27 +1461,36 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
         }
     }
     if (want_stats) {
-        float* sst = (float*)dsm;   // halo buffers are dead
+        // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
+        // fixed-point add per channel and workgroup (common.h: stat_add)
+        float* sst = (float*)dsm;                      // [NW][2][BQ]
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < 2 * BQ) sst[tid] = 0.f;
+        for (int i = tid; i < NW * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
+        float* mine = sst + wave * 2 * BQ;
 #pragma unroll
         for (int ni = 0; ni < NS; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
                 if (fr == 0) {
-                    atomicAdd(sst + ni * 16 + 4 * fk + r, x1);
-                    atomicAdd(sst + BQ + ni * 16 + 4 * fk + r, x2);
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
                 }
             }
         }
         __syncthreads();
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-        if (tid < 2 * BQ) {
-            const int which = tid / BQ, ql = tid - which * BQ;
-            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
+        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
+            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+            if (tid < 2 * BQ) {
+                const int which = tid / BQ, ql = tid - which * BQ;
+                float v = 0.f;
+                for (int w = 0; w < NW; ++w) v += sst[w * 2 * BQ + tid];
+                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
+            }
+        } else {
+            stats_publish(sst, NW, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
         }
     }
 }

@@ -55,7 +55,7 @@ __device__ __forceinline__ void ldf8g(const float* p, float f[8]) {
 __global__ __launch_bounds__(256) void gate_psi_kernel(const unsigned short* zg, const unsigned short* zx,
                                                        const float* sg, const float* hg, const float* sx,
                                                        const float* hx, const float* wpsi, float* psi_pre,
-                                                       float* stats, int64_t M, int F, int64_t ppb) {
+                                                       long long* stats, int64_t M, int F, int64_t ppb) {
     __shared__ float part[256];
     __shared__ float s4[4];
     const CGMap3 mp(F);
@@ -92,9 +92,8 @@ __global__ __launch_bounds__(256) void gate_psi_kernel(const unsigned short* zg,
         const float a = block_sum1(t1, s4);
         const float b = block_sum1(t2, s4);
         if (tid == 0) {
-            float* r = stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2;
-            atomicAdd(r, a);
-            atomicAdd(r + 1, b);
+            stat_add(stats, 1, (int)(blockIdx.x % AAU_STAT_REPLICAS), 0, 0, a);
+            stat_add(stats, 1, (int)(blockIdx.x % AAU_STAT_REPLICAS), 1, 0, b);
         }
     }
 }
@@ -313,7 +312,7 @@ using namespace aau;
 #define CHK_F(fn, C) AAU_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) <= 2048, fn ": channels=%d must be a multiple of 8 in [8, 2048]", (int)(C))
 
 extern "C" int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float* sg, const float* hg,
-                            const float* sx, const float* hx, const float* wpsi, float* psi_pre, float* stats,
+                            const float* sx, const float* hx, const float* wpsi, float* psi_pre, aau_stat* stats,
                             int64_t M, int F, void* stream) {
     AAU_REQUIRE(zg && zx && sg && hg && sx && hx && wpsi && psi_pre && M > 0, "aau_gate_psi: bad args");
     CHK_F("aau_gate_psi", F);
@@ -326,7 +325,7 @@ extern "C" int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float*
     b = (M + ppb - 1) / ppb;
     if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(gate_psi_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, zg, zx, sg, hg, sx, hx,
-                       wpsi, psi_pre, stats, M, F, ppb);
+                       wpsi, psi_pre, (long long*)stats, M, F, ppb);
     return check_launch("aau_gate_psi");
 }
 

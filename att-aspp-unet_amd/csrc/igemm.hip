@@ -331,27 +331,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     if (want_stats) {
         // per-wave row sums (DPP), combined across the waves in LDS (the tiles are dead now),
         // then ONE global atomic per channel and workgroup
-        float* sst = (float*)smem;                      // [2][BQ]
+        // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
+        // fixed-point add per channel and workgroup (common.h: stat_add)
+        float* sst = (float*)smem;                      // [4][2][BQ]
         __syncthreads();                                // every wave is done reading the LDS tiles
-        if (tid < 2 * BQ) sst[tid] = 0.f;
+        for (int i = tid; i < 4 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
+        float* mine = sst + wave * 2 * BQ;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
                 if (fr == 0) {
-                    atomicAdd(sst + wq * 48 + ni * 16 + 4 * fk + r, x1);
-                    atomicAdd(sst + BQ + wq * 48 + ni * 16 + 4 * fk + r, x2);
+                    mine[wq * 48 + ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + wq * 48 + ni * 16 + 4 * fk + r] = x2;
                 }
             }
         }
         __syncthreads();
-        float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-        if (tid < 2 * BQ) {
-            const int which = tid / BQ, ql = tid - which * BQ;
-            if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, sst[tid]);
-        }
+        stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -444,8 +443,8 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
 
 extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
                               aau_bf16* dst, const float* bias, const float* scale, const float* shift,
-                              float* stats, void* stream) {
-    return conv_dispatch(d, src, wpk, dst, bias, scale, shift, stats, nullptr, stream);
+                              aau_stat* stats, void* stream) {
+    return conv_dispatch(d, src, wpk, dst, bias, scale, shift, (float*)stats, nullptr, stream);
 }
 
 extern "C" int aau_conv_is_halo3x3(const aau_conv_desc* d) {

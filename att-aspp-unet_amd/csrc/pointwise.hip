@@ -36,7 +36,7 @@ __device__ __forceinline__ void block_sum8b(float acc[8], float* red, const CGMa
 
 // ---- first layer forward: z[m][c] = sum_t x[m+t] * w[c][t]; stats of z ----
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* x, const float* w, unsigned short* z,
-                                                        float* stats, int N, int H, int W, int C, int64_t ppb) {
+                                                        long long* stats, int N, int H, int W, int C, int64_t ppb) {
     extern __shared__ float sm[];  // [C*9] weights, then [256*8] reduction scratch
     float* sw = sm;
     float* sred = sm + C * 9;
@@ -69,17 +69,17 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* x, const fl
             if (z) *(u32x4*)(z + m * C + c) = pack8(o);   // z == null: statistics only, consumers recompute z
         }
     }
-    if (stats) {
-        float* r = stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * C;
+    if (stats) {   // order-independent fixed-point adds (common.h: stat_add)
+        const int rep = (int)(blockIdx.x % AAU_STAT_REPLICAS);
         block_sum8b(s1, sred, mp, tid);
         if (tid < mp.CG) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s1[j]);
+            for (int j = 0; j < 8; ++j) stat_add(stats, C, rep, 0, c + j, s1[j]);
         }
         block_sum8b(s2, sred, mp, tid);
         if (tid < mp.CG) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
+            for (int j = 0; j < 8; ++j) stat_add(stats, C, rep, 1, c + j, s2[j]);
         }
     }
 }
@@ -560,7 +560,7 @@ using namespace aau;
 
 #define CHK_C(fn, C) AAU_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) <= 2048, fn ": C=%d must be a multiple of 8 in [8, 2048]", (int)(C))
 
-extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, float* stats, int N, int H, int W, int C,
+extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, aau_stat* stats, int N, int H, int W, int C,
                              void* stream) {
     AAU_REQUIRE(x && w && (z || stats) && N > 0 && H > 0 && W > 0, "aau_conv1_fwd: bad args");
     AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_conv1_fwd: pixel count overflows int32");
@@ -571,7 +571,7 @@ extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, float*
     if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), (C * 9 + 256 * 8) * sizeof(float),
-                       (hipStream_t)stream, x, w, z, stats, N, H, W, C, ppb);
+                       (hipStream_t)stream, x, w, z, (long long*)stats, N, H, W, C, ppb);
     return check_launch("aau_conv1_fwd");
 }
 
@@ -670,6 +670,31 @@ extern "C" int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float*
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, out, C,
                        (float*)nullptr);
     return check_launch("aau_colsum");
+}
+
+// out[i] += (sum over the replicas of statistic `which`, channel c_begin + i) of a fixed-point statistics buffer
+__global__ void fold_stats_kernel(const long long* stats, int C, int which, int c_begin, int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += (float)stat_total(stats, C, which, c_begin + i);
+}
+__global__ void stats_to_f64_kernel(const long long* stats, int C, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * C) out[i] = stat_total(stats, C, i / C, i % C);
+}
+
+extern "C" int aau_fold_stats(const aau_stat* stats, int C, int which, int c_begin, int n, float* out, void* stream) {
+    AAU_REQUIRE(stats && out && C > 0 && (which == 0 || which == 1) && c_begin >= 0 && n > 0 && c_begin + n <= C,
+                "aau_fold_stats: bad args");
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(fold_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, C,
+                       which, c_begin, n, out);
+    return check_launch("aau_fold_stats");
+}
+extern "C" int aau_stats_to_f64(const aau_stat* stats, int C, double* out, void* stream) {
+    AAU_REQUIRE(stats && out && C > 0, "aau_stats_to_f64: bad args");
+    hipLaunchKernelGGL(stats_to_f64_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)stats, C, out);
+    return check_launch("aau_stats_to_f64");
 }
 
 extern "C" int aau_f32_to_bf16(const float* src, aau_bf16* dst, int64_t n, void* stream) {

@@ -335,7 +335,10 @@ class Plan:
         self.drop_p = eng.dropout_p() if train else 0.0
         st = eng.store
         nbn = st.bn_channels + 8
-        self.stats_arena = _Arena(STAT_REPLICAS * 2 * nbn, self.dev)
+        # order-independent fixed-point statistics (include/aau.h: aau_stat): int64 arenas, zeroed once per pass
+        self.stats_arena = _Arena(STAT_REPLICAS * 4 * nbn + 4 * 64, self.dev, dtype=torch.int64)
+        self.bstats_arena = _Arena(STAT_REPLICAS * 4 * 48 * eng.store.convs["d1.0.block.0"].O + 64, self.dev,
+                                   dtype=torch.int64) if train else None     # channel sums of dcat (4 levels x 3*Co)
         self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3 + STAT_REPLICAS * nbn * 3, self.dev)
         self.vec_arena = _Arena(nbn * 8 + 64, self.dev)
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
@@ -353,7 +356,7 @@ class Plan:
 
     def bnbuf(self, C_):
         va = self.vec_arena
-        return dict(stats=self.stats_arena.take(STAT_REPLICAS * 2 * C_), scale=va.take(C_), shift=va.take(C_),
+        return dict(stats=self.stats_arena.take(ops.stat_words(C_)), scale=va.take(C_), shift=va.take(C_),
                     mean=va.take(C_), invstd=va.take(C_), red=self.red_arena.take(STAT_REPLICAS * 2 * C_))
 
     def _bn_finalize(self, bn: BNP, w, count):
@@ -650,7 +653,7 @@ class Plan:
             self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co, feeds=blk["ra"])
             dcat = self.new(Mo, 2 * Co)
             # channel sums of dcat (fp32, from the data-gradient epilogue) -> ConvTranspose2d bias gradient below
-            sA = None if eng.no_fuse_colsum else self.red_arena.take(STAT_REPLICAS * 2 * 2 * Co)
+            sA = None if eng.no_fuse_colsum else self.bstats_arena.take(ops.stat_words(2 * Co))
             self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=2 * Co, din_stats=sA)
             if gate_kinds[lv] is None:
                 dskip[lv] = dcat
@@ -664,7 +667,7 @@ class Plan:
                       dskip[lv], Co, ds, gt["rep"], psi.dw, psi.dbias, Mo, Fi, Co)
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], ds, wg.dw)
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], ds, wx.dw)
-                sB = None if sA is None else self.red_arena.take(STAT_REPLICAS * 2 * Co)
+                sB = None if sA is None else self.bstats_arena.take(ops.stat_words(Co))
                 b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, 2 * Co, Cpad=wg.cpad_d,
                                                       accumulate=1), ds, wg.pk_d, dcat[:, Co:], None, None, None, sB)
                 b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, Co, Cpad=wx.cpad_d,
@@ -691,7 +694,7 @@ class Plan:
                     b.fork()
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], dzg, wg.dw, side=ov)
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], dzx, wx.dw, side=ov)
-                sB = None if sA is None else self.red_arena.take(STAT_REPLICAS * 2 * Co)
+                sB = None if sA is None else self.bstats_arena.take(ops.stat_words(Co))
                 b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Fi, Fi, ho, wo, Co, 2 * Co, Cpad=wg.cpad_d,
                                                       accumulate=1), dzg, wg.pk_d, dcat[:, Co:], None, None, None,
                       sB)
@@ -703,9 +706,9 @@ class Plan:
             if sA is None:
                 b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, rep_ws, Mo, Co)
             else:
-                b.add("aau_fold_replicas", sA[Co:], 2 * 2 * Co, up.dbias, Co)
+                b.add("aau_fold_stats", sA, 2 * Co, 0, Co, Co, up.dbias)      # channel sums of dcat[:, Co:]
                 if gt is not None:
-                    b.add("aau_fold_replicas", sB, 2 * Co, up.dbias, Co)
+                    b.add("aau_fold_stats", sB, Co, 0, 0, Co, up.dbias)
             ov = eng.overlap_wgrad
             if ov:
                 b.fork()        # dcat[:, Co:] is final (gate data-gradient accumulated above)
@@ -802,6 +805,7 @@ class Plan:
         if dlogits is not None and dlogits.data_ptr() != self.dlogits.data_ptr():
             self.dlogits.copy_(dlogits.reshape(self.dlogits.shape), non_blocking=True)
         self.red_arena.buf.zero_()
+        self.bstats_arena.buf.zero_()
         st.gflat.zero_()
 
     def run_backward(self, dlogits: torch.Tensor | None):

@@ -34,6 +34,27 @@ def _seed_ptr(seed, drop_p):
     return t.data_ptr(), t
 
 
+def stat_words(C: int) -> int:
+    """int64 words of an order-independent statistics buffer for C channels (aau.h: AAU_STAT_WORDS)."""
+    return STAT_REPLICAS * 2 * C * 2 + 2
+
+
+def stats_buffer(C: int, device="cuda") -> torch.Tensor:
+    """Zeroed aau_stat buffer (int64) for C channels."""
+    return torch.zeros(stat_words(C), dtype=torch.int64, device=device)
+
+
+def stats_totals(stats: torch.Tensor, C: int) -> torch.Tensor:
+    """fp64 [2, C]: (sum, sum of squares) per channel of an aau_stat buffer."""
+    out = torch.empty(2, C, dtype=torch.float64, device=stats.device)
+    check(fn("aau_stats_to_f64")(_p(stats), C, _p(out), _stream()), "aau_stats_to_f64")
+    return out
+
+
+def fold_stats(stats, C, which, c_begin, n, out):
+    check(fn("aau_fold_stats")(_p(stats), C, which, c_begin, n, _p(out), _stream()), "aau_fold_stats")
+
+
 def pitch_of(t: torch.Tensor) -> int:
     """Pixel pitch (elements) of an NHWC tensor/view whose last dim is contiguous."""
     assert t.stride(-1) == 1, "channel dimension must be contiguous"

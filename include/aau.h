@@ -37,9 +37,15 @@ extern "C" {
 #define AAU_E_INVALID (-1)     /* bad argument / unsupported shape */
 #define AAU_E_HIP (-2)         /* HIP runtime error at launch */
 
-#define AAU_STAT_REPLICAS 32   /* BN statistic accumulators are [REPLICAS][2][C] fp32 */
+#define AAU_STAT_REPLICAS 32   /* statistic accumulators are spread over this many replicas (same-address atomics) */
 
 typedef uint16_t aau_bf16;
+/* Per-channel batch statistics (sum, sum of squares) accumulated ORDER-INDEPENDENTLY: int64              */
+/* [AAU_STAT_REPLICAS][2][C][2 limbs] followed by one poison word (+1 pad); value = hi*2^-8 + lo*2^-52, added  */
+/* with 64-bit integer atomics, so the totals are the same bits for every arrival order (BatchNorm batch      */
+/* statistics no longer differ from run to run).  The caller zeroes the buffer (AAU_STAT_WORDS(C) words).     */
+typedef int64_t aau_stat;
+#define AAU_STAT_WORDS(C) ((size_t)AAU_STAT_REPLICAS * 2 * (size_t)(C) * 2 + 2)
 
 const char* aau_last_error(void);
 int aau_version(void);
@@ -90,12 +96,13 @@ typedef struct aau_conv_desc {
 /* wpk: bf16 [Cout][KH*KW][Cpad]; bias/scale/shift: optional fp32 [Cout] (NULL = none;    */
 /* [Co] and indexed by co when shuffle2x2);                                             */
 /* epi(v) = relu?( (v + bias) * scale + shift ).  stats (optional):                     */
-/* fp32 [AAU_STAT_REPLICAS][2][Cout], accumulates sum and sum of squares of v (pre-     */
-/* epilogue accumulator) per output channel -- the batch statistics of the following    */
-/* BatchNorm2d in training mode.  The caller zeroes stats beforehand.                   */
+/* aau_stat buffer for Cout channels (see the typedef): accumulates sum and sum of        */
+/* squares of v (pre-epilogue accumulator) per output channel, order-independently -- the */
+/* batch statistics of the following BatchNorm2d in training mode (read them with         */
+/* aau_bn_finalize / aau_fold_stats).  The caller zeroes stats beforehand.                */
 int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
                    aau_bf16* dst, const float* bias, const float* scale, const float* shift,
-                   float* stats, void* stream);
+                   aau_stat* stats, void* stream);
 
 /* Data-gradient conv (3x3, pad 1, stride 1, H and W multiples of 16: aau_conv_is_halo3x3)  */
 /* with the BatchNorm-backward REDUCE of the layer that produced the conv's input fused    */
@@ -146,7 +153,7 @@ int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* const* srcs
 int aau_traverse(int alternate);
 
 /* ---- first layer: Conv2d(1, C, 3, pad 1) on fp32 input (pipeline:113 d1[0]) --------- */
-int aau_conv1_fwd(const float* x, const float* w /*[C][9]*/, aau_bf16* z, float* stats,
+int aau_conv1_fwd(const float* x, const float* w /*[C][9]*/, aau_bf16* z, aau_stat* stats,
                   int N, int H, int W, int C, void* stream);
 int aau_conv1_wgrad(const float* x, const aau_bf16* dz, float* dw /*[C][9]*/,
                     int N, int H, int W, int C, void* stream);
@@ -172,7 +179,7 @@ int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_pack_entry* 
 /* ---- BatchNorm2d (pipeline:64 and every BN of :71-90) -------------------------------- */
 /* training: stats replicas -> mean / biased var -> scale = g*invstd, shift = b-mean*scale; */
 /* saves mean, invstd; running stats: momentum 0.1, unbiased var; nbt += 1.              */
-int aau_bn_finalize(const float* stats, const float* gamma, const float* beta,
+int aau_bn_finalize(const aau_stat* stats, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* scale, float* shift, float* save_mean, float* save_invstd,
                     int C, int64_t count, float eps, float momentum, void* stream);
@@ -246,7 +253,7 @@ int aau_spatial_sum(const aau_bf16* src, int src_pitch, aau_bf16* out, float* ws
 /* sumsq of psi_pre into stats [REPLICAS][2][1].                                           */
 int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float* sg, const float* hg,
                  const float* sx, const float* hx, const float* wpsi, float* psi_pre,
-                 float* stats, int64_t M, int F, void* stream);
+                 aau_stat* stats, int64_t M, int F, void* stream);
 /* alpha[m] = sigmoid(psi_pre*scale1+shift1); out[m,c] = x[m,c]*alpha[m]                   */
 int aau_gate_apply(const aau_bf16* x, int x_pitch, const float* psi_pre, const float* scale1,
                    const float* shift1, float* alpha, aau_bf16* out, int out_pitch, int64_t M,
@@ -311,6 +318,11 @@ int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float* ws, int64_
 /* of the `stats` a conv epilogue accumulated -- the ConvTranspose2d bias gradient is the        */
 /* channel sum of the gradient that the preceding data-gradient convs produced.                 */
 int aau_fold_replicas(const float* ws, int stride, float* out, int n, void* stream);
+/* out[i] += total of statistic `which` (0 sum, 1 sum of squares) of channel c_begin + i of an aau_stat buffer   */
+/* for C channels (e.g. the ConvTranspose2d bias gradient = channel sums that a data-gradient conv accumulated) */
+int aau_fold_stats(const aau_stat* stats, int C, int which, int c_begin, int n, float* out, void* stream);
+/* out fp64 [2][C] = the totals of an aau_stat buffer (NaN if poisoned by a non-finite partial)                   */
+int aau_stats_to_f64(const aau_stat* stats, int C, double* out, void* stream);
 
 /* Residual gate of the ablation variant (test_ablation.py:128-143; no BatchNorm, bias on psi):     */
 /*   alpha[m] = sigmoid(sum_f wpsi[f]*relu(zg[m,f]+zx[m,f]) + bpsi);  out[m,c] = x[m,c]*alpha[m] + x[m,c] */

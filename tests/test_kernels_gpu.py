@@ -76,13 +76,13 @@ def test_resident_weight_3x3_path(ops, case):
     cpad = ops.cpad_of(Cin)
     d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout + 8, 3, 3, 1, 1, 1, cpad, relu=1)
     out = torch.zeros(N, H, W, Cout + 8, dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = ops.stats_buffer(Cout)
     ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(pack_fwd(w, cpad)), out, bias=dev(bias), stats=stats)
     torch.cuda.synchronize()
     got = out.cpu()
     assert rel_err(got[..., :Cout], ref) < 6e-3
     assert float(got[..., Cout:].abs().max()) == 0
-    s = stats.sum(0).cpu()
+    s = ops.stats_totals(stats, Cout).float().cpu()
     assert float((s[0] - raw.sum(0)).abs().max()) < 2e-3 * float(raw.abs().sum(0).max())
     assert torch.allclose(s[1], (raw ** 2).sum(0), rtol=2e-3)
 
@@ -98,11 +98,11 @@ def test_igemm_forward_and_stats(ops, case):
     d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, dil * (k // 2), dil, cpad)
     xd, wd = dev(x.to(torch.bfloat16)), dev(pack_fwd(w, cpad))
     out = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = ops.stats_buffer(Cout)
     ops.conv_igemm(d, xd, wd, out, stats=stats)
     torch.cuda.synchronize()
     assert rel_err(out.cpu(), ref) < 6e-3
-    s = stats.sum(0).cpu()
+    s = ops.stats_totals(stats, Cout).float().cpu()
     flat = ref.reshape(-1, Cout)
     assert float((s[0] - flat.sum(0)).abs().max()) < 2e-3 * float(flat.abs().sum(0).max())
     assert torch.allclose(s[1], (flat ** 2).sum(0), rtol=2e-3)
@@ -143,14 +143,14 @@ def test_resident_weight_1x1_path(ops, case):
     xd, wd = dev(xw.to(torch.bfloat16)), dev(pack_fwd(w, cpad))
     wide = torch.zeros(N, H, W, Cout + 16, dtype=torch.bfloat16, device="cuda")
     d = ops.conv_desc(N, H, W, Cin, Cin + 8, H, W, Cout, Cout + 16, Cpad=cpad)
-    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = ops.stats_buffer(Cout)
     ops.conv_igemm(d, xd[..., 8:], wd, wide[..., 8:], stats=stats)
     torch.cuda.synchronize()
     got = wide.cpu()
     assert rel_err(got[..., 8:8 + Cout], raw) < 6e-3
     assert float(got[..., :8].abs().max()) == 0 and float(got[..., 8 + Cout:].abs().max()) == 0
     flat = raw.reshape(-1, Cout)
-    st = stats.sum(0).cpu()
+    st = ops.stats_totals(stats, Cout).float().cpu()
     assert float((st[0] - flat.sum(0)).abs().max()) < 2e-3 * float(flat.abs().sum(0).max())
     assert torch.allclose(st[1], (flat ** 2).sum(0), rtol=2e-3)
     # epilogue: bias, affine, ReLU, accumulate into the existing destination
@@ -200,7 +200,7 @@ def test_halo3x3_epilogue_bias_affine_relu_accumulate_pitch(ops):
     wide = torch.zeros(N, H, W, Cout + 16, dtype=torch.bfloat16, device="cuda")
     wide[..., 8:8 + Cout] = dev(prev.to(torch.bfloat16))
     d = ops.conv_desc(N, H, W, Cin, Cin + 8, H, W, Cout, Cout + 16, 3, 3, 1, 1, 1, cpad, accumulate=1, relu=1)
-    stats = torch.zeros(ops.STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = ops.stats_buffer(Cout)
     ops.conv_igemm(d, dev(xw.to(torch.bfloat16))[..., 8:], dev(pack_fwd(w, cpad)), wide[..., 8:], bias=dev(bias),
                    scale=dev(scale), shift=dev(shift), stats=stats)
     torch.cuda.synchronize()
@@ -208,7 +208,7 @@ def test_halo3x3_epilogue_bias_affine_relu_accumulate_pitch(ops):
     assert rel_err(got[..., 8:8 + Cout], ref) < 8e-3
     assert float(got[..., :8].abs().max()) == 0 and float(got[..., 8 + Cout:].abs().max()) == 0
     raw = R.conv_fwd(x, w).reshape(-1, Cout)
-    assert torch.allclose(stats.sum(0).cpu()[1], (raw ** 2).sum(0), rtol=2e-3)
+    assert torch.allclose(ops.stats_totals(stats, Cout).float().cpu()[1], (raw ** 2).sum(0), rtol=2e-3)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 48, 48, 3, 1), (1, 32, 32, 64, 96, 3, 6), (2, 8, 8, 96, 192, 1, 1),
