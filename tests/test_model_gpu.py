@@ -133,11 +133,26 @@ def test_trained_step_gradients_match_reference(A, golden):
     cos = float(torch.dot(ge, gr) / ge.norm() / gr.norm())
     assert cos > 0.9995, cos
     assert abs(float(ge.norm()) - float(g5["grad_norm"])) < 0.01 * float(g5["grad_norm"])
-    errs = sorted((rel(p.grad, g5["grad/" + k]), k) for k, p in named)
-    med, p90, worst = errs[len(errs) // 2][0], errs[int(len(errs) * 0.9)][0], errs[-1]
-    assert med < 0.04, (med, p90, worst)
-    assert p90 < 0.15, (med, p90, worst)
-    assert worst[0] < 0.6, worst
+    # Per-tensor table (scripts/grad_table.py prints it; round 2, deterministic BatchNorm statistics): median max-norm
+    # error 1.7 %, 90th percentile 6.4 %.  Every tensor above 10 % carries < 0.05 % of the gradient norm and is a
+    # near-cancelling sum: the scalar psi bias of u3 (40 %), the BatchNorm bias of the ASPP projection (26 %) and of
+    # d4.0 (13 %), and three weight tensors of the 8x8 / 16x16 levels (d4.1, bridge.project.0, bridge.blocks.2.0: 11-13 %
+    # in max norm, 3-6 % in L2).  So: tight L2 bounds where the gradient lives, an absolute bound (relative to the global
+    # norm) everywhere, and the max-norm statistics as a regression guard.
+    G = float(gr.double().norm())
+    rows = []
+    for k, p in named:
+        r = torch.from_numpy(g5["grad/" + k]).double()
+        e = p.grad.detach().double().cpu()
+        rows.append((rel(e, r), float((e - r).norm() / (r.norm() + 1e-30)), float((e - r).norm() / G), float(r.norm() / G), k))
+    errs = sorted(r[0] for r in rows)
+    med, p90, worst = errs[len(errs) // 2], errs[int(len(errs) * 0.9)], max(rows)
+    assert med < 0.03, (med, p90, worst)
+    assert p90 < 0.09, (med, p90, worst)
+    assert worst[0] < 0.5, worst
+    heavy = [r for r in rows if r[3] >= 1e-3]                # the tensors that carry 99.99 % of the gradient
+    assert len(heavy) >= 30 and max(r[1] for r in heavy) < 0.07, sorted(heavy, key=lambda r: -r[1])[:3]
+    assert max(r[2] for r in rows) < 5e-3, sorted(rows, key=lambda r: -r[2])[:3]
     for k, p in named:  # gradients are views of the engine's flat buffer with the parameter's own strides
         assert p.grad.shape == p.shape and p.grad.stride() == p.stride()
 
@@ -213,7 +228,10 @@ def test_optimizer_step_and_short_training_tracks_oracle(A):
     ue = torch.cat([p.detach().cpu().flatten() for p in m.parameters()]) - init
     ur = torch.cat([p.detach().flatten() for p in ref.parameters()]) - init
     cos = float(torch.dot(ue, ur) / ue.norm() / ur.norm())
-    assert cos > 0.3, cos
+    print(dict(curve_max_dev=float(np.abs(le_ - lr_).max() / lr_.max()), first3=float(np.abs(le_[:3] - lr_[:3]).max()), cos=cos))
+    # 0.46 measured: after 20 sign-like Adam steps on a 64x64 problem the two trajectories have separated element by
+    # element while the losses still agree to a few percent - this is a guard against a wrong update rule, not a metric
+    assert cos > 0.4, cos
 
 
 @pytest.mark.parametrize("cfg", [dict(base_c=16, B=3, H=64, W=96), dict(base_c=8, B=2, H=48, W=32, rates=(2, 5, 9)),
@@ -314,3 +332,59 @@ def test_dropout_draws_a_new_mask_every_step_also_under_graph_replay(A):
         m.eval()
         e = m(x)
         assert float((r1 - r2).abs().max()) < 2.0 * float(e.abs().max()) + 1.0
+
+
+def _g7_model(A, golden):
+    g = golden("g7_trained_c16_256.npz")
+    sd = {}
+    for k, v in g.items():
+        if k.startswith("sd_bf16/"):
+            sd[k[8:]] = torch.from_numpy(v.copy()).view(torch.bfloat16).float()
+        elif k.startswith("sd_raw/"):
+            sd[k[7:]] = torch.from_numpy(v.copy())
+    m = A.AttentionASPPUNet(base_c=16)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda(), g
+
+
+def test_realistic_width_dice_within_1e3_of_reference(A, golden):
+    """base_c 16, 1x256x256, weights trained with the REFERENCE (oracle/make_golden_c16.py): the BASELINE.json bar
+    |Dice_build - Dice_ref| <= 1e-3 at a realistic width, for evaluate() (pipeline:235-241) and for the integer-count
+    Dice / IoU of eval_segmentation_batch.py:41-49 on the thresholded masks."""
+    m, g = _g7_model(A, golden)
+    m.eval()
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    with torch.no_grad():
+        l = m(x)
+    ref_l = torch.from_numpy(g["eval_logits"].astype(np.float32))
+    assert rel(l, ref_l) < 1.5e-2, rel(l, ref_l)
+    d, i = A.evaluate(m, [(x[:4], y[:4]), (x[4:], y[4:])], torch.device("cuda"))
+    assert abs(d - float(g["evaluate_dice"])) < 1e-3 and abs(i - float(g["evaluate_iou"])) < 1e-3, (d, i)
+    masks = (torch.sigmoid(l) > 0.5).to(torch.uint8)[:, 0]
+    gts = (y[:, 0] > 0).to(torch.uint8)
+    for k in range(8):
+        assert abs(A.evalseg.dice(masks[k], gts[k]) - float(g["seg_dice"][k])) < 1e-3, k
+        assert abs(A.evalseg.iou(masks[k], gts[k]) - float(g["seg_iou"][k])) < 2e-3, k
+        assert abs(int(masks[k].sum()) - int(g["mask_counts"][k])) <= max(8, 0.002 * int(g["mask_counts"][k])), k
+    tta = A.predict_prob_tta(m, x[:1])
+    assert np.abs(tta - g["tta_prob0"].astype(np.float32)).max() < 2e-2
+    assert float(np.mean((tta > 0.5) != (g["tta_prob0"].astype(np.float32) > 0.5))) < 1e-3
+
+
+def test_realistic_width_train_step_matches_reference(A, golden):
+    m, g = _g7_model(A, golden)
+    m.train()
+    m.bridge.project[3].p = 0.0
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    crit = A.build_criterion(main_args(), A.ComboLoss(), A.EdgeLoss())
+    loss = crit(m(x), y)
+    loss.backward()
+    assert abs(loss.item() - float(g["train_loss"])) < 2e-3 * float(g["train_loss"])
+    named = dict(m.named_parameters())
+    assert list(named) == list(g["grad_names"])
+    got = np.array([float(p.grad.double().norm()) for p in named.values()])
+    want = g["grad_norms"]
+    assert abs(np.linalg.norm(got) - float(g["grad_norm"])) < 0.01 * float(g["grad_norm"])
+    heavy = want >= 1e-3 * np.linalg.norm(want)
+    assert np.all(np.abs(got[heavy] - want[heavy]) < 0.05 * want[heavy]), \
+        sorted(zip(np.abs(got - want)[heavy] / want[heavy], np.array(list(named))[heavy]))[-3:]
