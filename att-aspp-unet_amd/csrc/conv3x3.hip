@@ -599,6 +599,282 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Column-step variant of the halo kernel (conv3x3h): the LDS READ traffic is what the grouped-tap kernel runs into.
+// There every wave owns 4 patch rows x BQ channels and reads, per tap, 4 pixel fragments + BQ/16 weight fragments for
+// 24 MFMAs: with two workgroups per CU that is 10 KB x 8 waves = 640 LDS cycles per tap against 768 MFMA cycles per
+// SIMD, plus the LDS-DMA writes -- LDS and matrix pipes co-limited.  Here
+//   * the four waves are a 2 x 2 grid: 8 patch rows x BQ/2 channels each (the same 24 accumulator tiles), and
+//   * a pipeline step is one tap COLUMN tx (taps tx, 3+tx, 6+tx): the 10 halo-row fragments a wave needs for the
+//     three vertical taps are read once and reused, only the 3 x BQ/32 weight fragments change,
+// so a step reads 10 + 9 fragments for 72 MFMAs (30 before): -37 % LDS reads, 3 barriers per chunk instead of 5.
+// The loop body is unrolled over 2 chunks x 3 columns, which makes every LDS address a loop-invariant register plus an
+// immediate (the swizzled halo offsets of the 30 (column, row) fragments are computed once; the first version spent
+// ~150 VALU instructions per step recomputing them and only then started its MFMAs), and the fragment reads and the
+// next step's LDS-DMA are interleaved INTO the MFMA stream (sched_group_barrier) instead of in front of it.
+// Every wave issues the same number of LDS-DMA instructions (the spare ones are all-out-of-range pieces that land in
+// a 1-KB scratch area), so the loop has no divergent code and the vmcnt counts are constants.
+// LDS: two halo buffers (42 KB) + 2 slots of 3 tap tiles (36 KB) + scratch = 79 KB -> two workgroups per CU.
+template <int BQ>
+__global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
+    static_assert(BQ % 32 == 0, "two channel halves of whole 16-channel tiles");
+    constexpr int BK = 32, HW_ = 18, HROWS = 324, NI = BQ / 32, MI = 8, QH = BQ / 2;
+    constexpr int HPIECES = 21;                    // 16-row pieces of a halo tile (336 rows staged, 324 used)
+    constexpr int WPIECES = 3 * BQ / 16;           // 16-row pieces of a column's three tap tiles
+    constexpr int WLW = (WPIECES + 3) / 4;         // ... per wave
+    constexpr int HALO_E = HPIECES * 16 * BK, WT_E = BQ * BK, SLOT_E = 3 * WT_E;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_h[];
+    unsigned short* smem = smem_h;
+    unsigned short* const scratch = smem + 2 * HALO_E + 2 * SLOT_E;     // 512 elements
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int rh = wave >> 1, qh = wave & 1;
+    const int ntq = (d.Cout + BQ - 1) / BQ;
+    const int nwg = gridDim.x;
+    int bid = a.rev ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tq = bid % ntq;
+    int patch = bid / ntq;
+    const int px_t = patch % a.tiles_x;
+    patch /= a.tiles_x;
+    const int py_t = patch % a.tiles_y;
+    const int n = patch / a.tiles_y;
+    const int q0 = tq * BQ, y0 = py_t * 16, x0 = px_t * 16;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+
+    // halo pieces p = i * 4 + wave (i < 6): 21 real ones, the three spare ones are out of range and land in `scratch`
+    unsigned hoff[6];
+    unsigned tailmask = 0;      // bit i: this lane's 8 channels of piece i exist in the LAST chunk
+    const int tail_c0 = (a.nchunk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+        const int lc = swz32(hr, lane & 3);
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = hr < HROWS && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+        hoff[i] = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc * 8) * 2) : OOB;
+        if (tail_c0 + lc * 8 < d.Cin) tailmask |= 1u << i;
+    }
+    const bool has_tail = d.Cpad != d.Cin;
+    // weight pieces p = j * 4 + wave (j < WLW): tap row k = p / (BQ/16), 16 output channels each
+    unsigned woff[WLW];
+#pragma unroll
+    for (int j = 0; j < WLW; ++j) {
+        const int p = j * 4 + wave;
+        const int k = p / (BQ / 16), row = (p - k * (BQ / 16)) * 16 + (lane >> 2);
+        const int lc = swz32(row, lane & 3);
+        const bool ok = p < WPIECES && (q0 + row) < d.Cout;
+        woff[j] = ok ? (unsigned)((((q0 + row) * 9 + 3 * k) * d.Cpad + lc * 8) * 2) : OOB;
+    }
+    auto issue_halo = [&](int chunk, int buf) {
+        const bool dead = chunk >= a.nchunk;
+        const bool last = has_tail && chunk == a.nchunk - 1;
+        unsigned short* base = smem + buf * HALO_E;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int p = i * 4 + wave;
+            const unsigned v = (dead || (last && !((tailmask >> i) & 1))) ? OOB : hoff[i];
+            unsigned short* dst = (p < HPIECES) ? base + p * 16 * BK : scratch;      // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst), 16, (int)v, chunk * BK * 2, 0, 0);
+        }
+    };
+    // column tx of a chunk = taps {tx, 3 + tx, 6 + tx}
+    auto issue_w = [&](int slot, int chunk, int tx) {
+        const bool dead = chunk >= a.nchunk;
+        const int soff = (tx * d.Cpad + chunk * BK) * 2;
+        unsigned short* base = smem + 2 * HALO_E + slot * SLOT_E;
+#pragma unroll
+        for (int j = 0; j < WLW; ++j) {
+            const int p = j * 4 + wave;
+            unsigned short* dst = (p < WPIECES) ? base + p * 16 * BK : scratch;      // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst), 16, (int)(dead ? OOB : woff[j]), soff, 0, 0);
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+    // loop-invariant LDS element offsets: pixel fragments (column tx, halo row rh*8 + r) inside a halo buffer ...
+    int aoff[3][MI + 2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < MI + 2; ++r) {
+            const int hr = (rh * MI + r) * HW_ + fr + t;
+            aoff[t][r] = hr * BK + swz32(hr, fk) * 8;
+        }
+    // ... and this lane's weight fragment inside a tap tile ((row >> 2) & 3 == (fr >> 2) & 3 for every channel tile)
+    const int boff = 2 * HALO_E + (qh * QH + fr) * BK + swz32(fr, fk) * 8;
+
+    // one pipeline step, all template-like arguments compile-time after unrolling
+    auto step = [&](const int buf, const int tx, const int slot, int chunk, const bool prev_halo) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);      // the previous step's MFMAs stay in front of this wait
+        if (prev_halo) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // only that halo tile may stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned short* hb = smem + buf * HALO_E;
+        const unsigned short* wb = smem + boff + slot * SLOT_E;
+        bf16x8 af[MI + 2], wf[3][NI];
+        // program order = order of need
+        wf[0][0] = *(const bf16x8*)(wb);
+#pragma unroll
+        for (int r = 0; r < MI; ++r) af[r] = *(const bf16x8*)(hb + aoff[tx][r]);
+#pragma unroll
+        for (int ni = 1; ni < NI; ++ni) wf[0][ni] = *(const bf16x8*)(wb + ni * 16 * BK);
+#pragma unroll
+        for (int k = 1; k < 3; ++k) {
+            wf[k][0] = *(const bf16x8*)(wb + k * WT_E);
+            af[MI - 1 + k] = *(const bf16x8*)(hb + aoff[tx][MI - 1 + k]);
+#pragma unroll
+            for (int ni = 1; ni < NI; ++ni) wf[k][ni] = *(const bf16x8*)(wb + k * WT_E + ni * 16 * BK);
+        }
+        // next column's weights (the slot read in the previous step), then -- at column 0 -- the next chunk's halo
+        {
+            int t2 = tx + 1, c2 = chunk;
+            if (t2 == 3) { t2 = 0; ++c2; }
+            issue_w(slot ^ 1, c2, t2);
+        }
+        if (tx == 0) issue_halo(chunk + 1, buf ^ 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][ni], af[mi + k], acc[ni][mi], 0, 0, 0);
+        // schedule: 4 reads, then one read per MFMA until the 10 + 3*NI fragments are in, then one LDS-DMA per 4 MFMAs
+        constexpr int NRD = MI + 2 + 3 * NI, NMF = 3 * NI * MI;
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < NRD - 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (tx == 0) {
+#pragma unroll
+            for (int i = 0; i < WLW + 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - (NRD - 4) - 4 * (WLW + 6), 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WLW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - (NRD - 4) - 4 * WLW, 0);
+        }
+    };
+
+    issue_halo(0, 0);
+    issue_w(0, 0, 0);
+    for (int c0 = 0; c0 < a.nchunk; c0 += 2) {
+        step(0, 0, 0, c0, false);
+        step(0, 1, 1, c0, true);
+        step(0, 2, 0, c0, false);
+        if (c0 + 1 >= a.nchunk) break;
+        step(1, 0, 1, c0 + 1, false);
+        step(1, 1, 0, c0 + 1, true);
+        step(1, 2, 1, c0 + 1, false);
+    }
+    // the out-of-range pieces issued by the last steps still write zeros into LDS: drain before LDS is reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue ----
+    const bool want_stats = a.stats != nullptr;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int y = y0 + rh * MI + mi, x = x0 + fr;
+        const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int q = q0 + qh * QH + ni * 16 + 4 * fk;
+            if (q >= d.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+            if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
+            if (a.bias) {
+                const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (a.scale) {
+                const f32x4 sc = *(const f32x4*)(a.scale + q);
+                const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+            }
+            unsigned short* out = a.dst + pixel * d.dst_pitch + q;
+            if (d.accumulate) {
+                const u32x2 old = *(const u32x2*)out;
+                v[0] += __uint_as_float(old[0] << 16);
+                v[1] += __uint_as_float(old[0] & 0xffff0000u);
+                v[2] += __uint_as_float(old[1] << 16);
+                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+            }
+            if (d.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            u32x2 pk;
+            pk[0] = pack2(v[0], v[1]);
+            pk[1] = pack2(v[2], v[3]);
+            *(u32x2*)out = pk;
+        }
+    }
+    if (want_stats) {
+        // every wave stores the row sums of ITS channel half in its own block (zero elsewhere); fixed wave order
+        float* sst = (float*)smem;                      // [4][2][BQ]
+        __syncthreads();
+        for (int i = tid; i < 4 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
+        __syncthreads();
+        float* mine = sst + wave * 2 * BQ + qh * QH;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0) {
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
+                }
+            }
+        }
+        __syncthreads();
+        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
+            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
+            if (tid < 2 * BQ) {
+                const int which = tid / BQ, ql = tid - which * BQ;
+                float v = 0.f;
+                for (int w = 0; w < 4; ++w) v += sst[w * 2 * BQ + tid];
+                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
+            }
+        } else {
+            stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // EXPERIMENT (opt-in, AAU_C3_LOADER=1; measured 25-30 % slower than conv3x3g, see conv3x3_launch):
 // the grouped-tap kernel with a DEDICATED LOADER WAVE (wave 4 of 5).  In conv3x3g every wave issues its share of the
 // LDS-DMA (~5 buffer_load ... lds per step); inside a wave that also runs 48 MFMAs and 20 ds_read_b128 per step each
@@ -1639,6 +1915,17 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
         if (narrow) hipLaunchKernelGGL((conv3x3l_kernel<48>), dim3((unsigned)grid), dim3(320), ldsl, s, a);
         else hipLaunchKernelGGL((conv3x3l_kernel<96>), dim3((unsigned)grid), dim3(320), ldsl, s, a);
         return check_launch("aau_conv_igemm(3x3 halo, grouped taps, loader wave)");
+    }
+    if (!wide_patch && !narrow && !getenv("AAU_C3_NOH") && !getenv("AAU_C3_NOGROUP") && !getenv("AAU_C3_LOADER")) {
+        static bool attrh = false;
+        if (!attrh) {
+            hipFuncSetAttribute((const void*)conv3x3h_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attrh = true;
+        }
+        prof_tag("conv3x3h<96>");
+        const size_t ldsh = (size_t)(2 * 336 * 32 + 2 * 3 * 96 * 32 + 512) * 2;
+        hipLaunchKernelGGL((conv3x3h_kernel<96>), dim3((unsigned)grid), dim3(256), ldsh, s, a);
+        return check_launch("aau_conv_igemm(3x3 halo, column steps)");
     }
     prof_tag(narrow ? "conv3x3g<48>" : "conv3x3g<96>");
     if (!wide_patch && !getenv("AAU_C3_NOGROUP")) {

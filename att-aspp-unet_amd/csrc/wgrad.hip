@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const WRedArgs a) {
                 sum += t0; sum += t1; sum += t2; sum += t3;
             }
             for (; t < nterms; t += a.P) sum += term(t);
-        } else {
+        } else {   // MODE 1 / 2
             lane = (int)(slot & 255);          // source thread id
             int64_t rest = slot >> 8;
             v = (int)(rest % a.NV);
@@ -331,6 +331,18 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const WRedArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (qb + r < a.Cout) a.dw[((int64_t)(qb + r) * a.T + tap) * a.Cin + c] += sum[r];
+    } else if constexpr (MODE == 2) {   // wgrad3x3r_kernel<QT = TQ, CJ = TC>: v = (i*3 + tx)*3 + ty
+        const int wave = lane >> 6, l = lane & 63;
+        const int jw = wave % a.TC, qg = wave / a.TC;
+        const int i = v / 9, tx = (v / 3) % 3, ty = v % 3;
+        const int tc = tile % a.ntc, tq = tile / a.ntc;
+        const int g16 = l >> 4, li = l & 15;
+        const int c = tc * 16 * a.TC + jw * 16 + li;
+        const int qb = tq * a.TQ * 16 + (qg * 3 + i) * 16 + 4 * g16;
+        if (c < a.Cin)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (qb + r < a.Cout) a.dw[((int64_t)(qb + r) * 9 + (ty * 3 + tx)) * a.Cin + c] += sum[r];
     } else {
         const int QT = a.NV / 7;
         const int wave = lane >> 6, l = lane & 63;
@@ -358,6 +370,7 @@ int wg_reduce_launch(int mode, WRedArgs& r, hipStream_t s) {
     const int VPB = 256 / P;
     const int64_t grid = (r.nslots + VPB - 1) / VPB;
     if (mode == 0) hipLaunchKernelGGL((wg_reduce_kernel<0>), dim3((unsigned)grid), dim3(256), 0, s, r);
+    else if (mode == 2) hipLaunchKernelGGL((wg_reduce_kernel<2>), dim3((unsigned)grid), dim3(256), 0, s, r);
     else hipLaunchKernelGGL((wg_reduce_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, r);
     return check_launch("aau_conv_wgrad(split-K reduce)");
 }
@@ -366,6 +379,11 @@ int wg_reduce_launch(int mode, WRedArgs& r, hipStream_t s) {
 bool wgrad3x3_applicable(const aau_conv_desc* d);
 int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
                     int64_t ws_bytes, int64_t* need, hipStream_t s);
+
+// wgrad3x3r.hip
+int wgrad3x3r_variant(const aau_conv_desc* d);
+int wgrad3x3r_launch(int variant, const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
+                     int64_t ws_bytes, int64_t* need, hipStream_t s);
 
 template <int TQ, int TC>
 static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
@@ -439,9 +457,16 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
     a.M = d->N * d->Ho * d->Wo;
     a.linear = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo);
     if (wgrad3x3_applicable(d)) {
-        if (need) return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream);
+        const int rv = wgrad3x3r_variant(d);
+        if (need) return rv ? wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream)
+                            : wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream);
         const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;
         ProfScope prof(1, flops, (hipStream_t)stream);
+        if (rv) {
+            prof_tag(rv == 1 ? "wgrad3x3r<3,4>" : "wgrad3x3r<6,2>",
+                     2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout) + 4.0 * d->Cout * 9.0 * d->Cin);
+            return wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream);
+        }
         prof_tag("wgrad3x3<3,8>", 2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout) + 4.0 * d->Cout * 9.0 * d->Cin);
         return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream);
     }

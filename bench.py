@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch table (every kernel of one step) to this file")
     ap.add_argument("--no-infer", action="store_true", help="skip the inference side numbers (configs 2 and 5)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("AAU_BENCH_GRAPH", "1")),
                     help="replay the step as one hipGraph when possible")
@@ -280,6 +281,18 @@ def main():
         torch.cuda.synchronize()
         _abi.prof_enable(False)
         recs = _abi.prof_collect_launches()
+        if a.dump_launches and len(recs) % nprof == 0:
+            per = len(recs) // nprof
+            with open(a.dump_launches, "w") as f:
+                tot = 0.0
+                for i in range(per):
+                    us = sum(recs[s_ * per + i]["ms"] for s_ in range(nprof)) / nprof * 1e3
+                    r0 = recs[i]
+                    tot += us
+                    gbs = r0["bytes"] / us / 1e3 if r0["bytes"] > 0 else 0.0
+                    f.write(f"{i:4d} {r0['family']:12s} {r0['label'][:44]:44s} {r0['tag'][:28]:28s} {us:8.1f} us  "
+                            f"{r0['bytes'] / 1e6:8.1f} MB {gbs:7.0f} GB/s  {r0['flops'] / 1e9:8.2f} GF\n")
+                f.write(f"total {tot:.1f} us over {per} launches\n")
         alg = train_gflop_per_image(a.base_c, a.size) * a.batch * 1e9
         roof = roofline_from_records(recs, nprof, alg, dt / a.steps, a.base_c, a.size, a.batch)
     # The reference loop hands HOST batches to the device every step (pipeline:319: 2 x 8 MB at bs 8).  `value` is

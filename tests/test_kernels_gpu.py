@@ -304,6 +304,15 @@ WGRAD_CASES = [
     (1, 16, 32, 200, 104, 3, 1),
     (3, 8, 16, 48, 144, 3, 1),
     (1, 64, 64, 24, 40, 3, 1),
+    # row-reuse 3x3 kernel (csrc/wgrad3x3r.hip): <3,4> = 48 q x 64 c tiles, <6,2> = 96 q x 32 c tiles, ragged tails
+    (2, 16, 32, 64, 48, 3, 1),
+    (1, 32, 32, 192, 96, 3, 1),
+    (2, 16, 16, 128, 144, 3, 1),
+    (1, 24, 48, 320, 40, 3, 1),
+    (2, 16, 32, 32, 96, 3, 1),
+    (1, 32, 16, 96, 192, 3, 1),
+    (1, 16, 16, 160, 288, 3, 1),
+    (5, 8, 16, 384, 384, 3, 1),
 ]
 
 

@@ -108,6 +108,24 @@ def test_trained_weights_eval_and_metrics(golden):
         np.testing.assert_allclose(O.predict_prob_tta(net, x[:1]), g["tta_prob0"], rtol=0, atol=1e-5)
 
 
+def test_realistic_width_fixture_pins_oracle(golden):
+    """base_c 16 / 256x256, weights trained with the reference (oracle/make_golden_c16.py): eval logits, evaluate() and the
+    integer-count Dice of eval_segmentation_batch.py:41-49 from the restatement on the stored (bf16-representable) weights."""
+    g = golden("g7_trained_c16_256.npz")
+    sd = {k[8:]: torch.from_numpy(v.copy()).view(torch.bfloat16).float() for k, v in g.items() if k.startswith("sd_bf16/")}
+    sd.update({k[7:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("sd_raw/")})
+    net = O.AttentionASPPUNet(base_c=16)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    with torch.no_grad():
+        lv = net(x[:4])
+    ref = g["eval_logits"][:4].astype(np.float32)
+    assert np.abs(lv.numpy() - ref).max() < 2e-3 * np.abs(ref).max() + 1e-3       # fixture logits are stored as fp16
+    d, i = O.evaluate(net, [(x[:4], y[:4]), (x[4:], y[4:])], torch.device("cpu"))
+    assert abs(d - float(g["evaluate_dice"])) < 1e-5 and abs(i - float(g["evaluate_iou"])) < 1e-5
+
+
 def test_legacy_key_rename():
     sd = {"u4.att.W_g.0.weight": 1, "u4.att.W_x.1.bias": 2, "d1.0.block.0.weight": 3}
     out = O.rename_legacy_keys(sd)
