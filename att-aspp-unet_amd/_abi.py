@@ -53,7 +53,6 @@ _SIGS = {
     "aau_conv_igemm": [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P],
     "aau_conv_is_halo3x3": [C.POINTER(ConvDesc)],
     "aau_traverse": [I],
-    "aau_conv_igemm_bnred": [C.POINTER(ConvDesc), P, P, P, P, I, P, P, P, P, P, P],
     "aau_conv_wgrad": [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P],
     "aau_conv_wgrad_ws_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int64)],
     "aau_conv_wgrad_group_ok": [C.POINTER(ConvDesc), I],
@@ -66,11 +65,11 @@ _SIGS = {
     "aau_bn_act": [P, I, P, I, P, P, L, I, I, L, F, P, P],
     "aau_bn_act_pool": [P, I, P, I, P, I, P, P, I, I, I, I, P],
     "aau_maxpool2": [P, I, P, I, I, I, I, I, P],
-    "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, P, P],
+    "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, P, P, P],
     "aau_bn_bwd_apply": [P, I, P, I, P, P, P, P, P, P, L, I, P, I, P, P, I, F, P, P],
     "aau_bn_bwd_apply_conv1": [P, I, P, P, P, P, P, P, I, I, I, I, P, I, P, P, P, P, P, P, P],
     "aau_conv1_bn_act": [P, P, P, I, P, P, I, I, I, I, P],
-    "aau_conv1_bn_bwd_reduce": [P, P, P, I, P, P, P, P, P, I, I, I, I, P],
+    "aau_conv1_bn_bwd_reduce": [P, P, P, I, P, P, P, P, P, I, I, I, I, P, P],
     "aau_gap_fwd": [P, I, P, P, I, I, I, P],
     "aau_gap_bwd": [P, P, I, I, I, I, P],
     "aau_spatial_sum": [P, I, P, P, I, I, I, P],
@@ -148,6 +147,8 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.argtypes = sig
             fn.restype = C.c_int
+        l.aau_bn_red_ws_bytes.restype = C.c_int64
+        l.aau_bn_red_ws_bytes.argtypes = [C.c_int]
         _lib = l
     return _lib
 

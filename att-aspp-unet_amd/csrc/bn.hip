@@ -173,7 +173,8 @@ template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const unsigned short* z, int zp, const unsigned short* dy, int dyp, const unsigned short* dpool, int dpp,
     unsigned short* dz, int dzp, const float* scale, const float* shift, const float* mean, const float* invstd,
-    float* red, int N, int H, int W, int C, int relu, float drop_p, const uint64_t* seedp, int64_t items_per_block) {
+    float* red, int N, int H, int W, int C, int relu, float drop_p, const uint64_t* seedp, int64_t items_per_block,
+    float* ws) {
     const uint64_t seed = drop_p > 0.f ? *seedp : 0;   // device-resident: a captured hipGraph sees a fresh value per replay
     __shared__ float sred[256 * 8];
     const CGMap mp(C);
@@ -253,16 +254,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             }
         }
     }
-    float* r = red + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * C;
+    // this workgroup's row [2][C] of partial sums; red_fold_launch adds the rows in a fixed order (common.h)
+    float* r = red_row(ws, 2 * C, blockIdx.x);
     block_sum8(s1, sred, mp, tid);
     if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s1[j]);
+        *(f32x4*)(r + c) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+        *(f32x4*)(r + c + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
     }
     block_sum8(s2, sred, mp, tid);
     if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
+        *(f32x4*)(r + C + c) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+        *(f32x4*)(r + C + c + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
     }
 }
 
@@ -279,11 +281,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     const uint64_t seed = drop_p > 0.f ? *seedp : 0;
     extern __shared__ float sm[];   // [2][C] replica sums, computed once per workgroup
     for (int cc = threadIdx.x; cc < C; cc += 256) {
-        float a = 0.f, b = 0.f;
-        for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
-            a += red[(size_t)r * 2 * C + cc];
-            b += red[(size_t)r * 2 * C + C + cc];
-        }
+        const float a = red[cc], b = red[C + cc];       // totals of the reduce pass
         sm[cc] = a;
         sm[C + cc] = b;
         if (blockIdx.x == 0) {
@@ -360,11 +358,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
     if (!z)
         for (int i = threadIdx.x; i < C * 9; i += 256) swc[i] = wconv[i];
     for (int cc = threadIdx.x; cc < C; cc += 256) {
-        float a = 0.f, b = 0.f;
-        for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
-            a += red[(size_t)r * 2 * C + cc];
-            b += red[(size_t)r * 2 * C + C + cc];
-        }
+        const float a = red[cc], b = red[C + cc];       // totals of the reduce pass
         sm[cc] = a;
         sm[C + cc] = b;
         if (blockIdx.x == 0) {
@@ -476,6 +470,45 @@ __global__ void fold_conv1_kernel(const float* ws, float* dw, int n) {
 }
 
 // rows per block so that the grid is ~8 workgroups per CU and every thread gets a few iterations
+// ---- fixed-order sum of the workgroup rows (common.h: red_fold_launch) ----
+// A workgroup owns 4 consecutive 16-B vectors of the row (64 B) and 64 row lanes: thread (rl, v) adds rows rl, rl+64, ..
+// in that order, the 64 partial sums are then added in lane order.
+__global__ __launch_bounds__(256) void red_fold_kernel(const float* ws, int n, int nblk, float* out, int n_out, float* acc,
+                                                       int n_acc, float* acc2) {
+    __shared__ f32x4 sm[256];
+    const int v = (int)blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
+    const int nv = n >> 2;
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (v < nv) {
+        const float* p = ws + (size_t)v * 4;
+        int r = rl;
+        for (; r + 192 < nblk; r += 256) {      // 4 independent loads in flight, fixed order of the additions
+            const f32x4 t0 = *(const f32x4*)(p + (size_t)r * n), t1 = *(const f32x4*)(p + (size_t)(r + 64) * n);
+            const f32x4 t2 = *(const f32x4*)(p + (size_t)(r + 128) * n), t3 = *(const f32x4*)(p + (size_t)(r + 192) * n);
+            a += t0; a += t1; a += t2; a += t3;
+        }
+        for (; r < nblk; r += 64) a += *(const f32x4*)(p + (size_t)r * n);
+    }
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (rl != 0 || v >= nv) return;
+    for (int k = 1; k < 64; ++k) a += sm[k * 4 + (threadIdx.x & 3)];
+    const int i = v * 4;
+    if (i < n_out) {
+        *(f32x4*)(out + i) = a;
+    } else if (i < n_out + n_acc) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i - n_out + k] += a[k];
+    } else if (i == n_out + n_acc && acc2) {
+        acc2[0] += a[0];
+    }
+}
+
+int red_fold_launch(const float* ws, int n, int nblk, float* out, int n_out, float* acc, int n_acc, float* acc2, hipStream_t s) {
+    hipLaunchKernelGGL(red_fold_kernel, dim3((unsigned)((n / 4 + 3) / 4)), dim3(256), 0, s, ws, n, nblk, out, n_out, acc, n_acc, acc2);
+    return check_launch("red_fold");
+}
+
 static inline void rows_split(int64_t M, int PL, int64_t* blocks, int64_t* ppb) {
     int64_t b = (M + (int64_t)PL * 4 - 1) / ((int64_t)PL * 4);
     if (b > 2048) b = 2048;
@@ -565,12 +598,18 @@ extern "C" int aau_maxpool2(const aau_bf16* y, int y_pitch, aau_bf16* p, int p_p
     return check_launch("aau_maxpool2");
 }
 
+extern "C" int64_t aau_bn_red_ws_bytes(int C) {
+    if (C <= 0) return 0;
+    return (int64_t)red_ws_floats(3 * C + 8, AAU_BN_RED_MAX_BLOCKS) * (int64_t)sizeof(float);
+}
+
 extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16* dy, int dy_pitch,
                                  const aau_bf16* dpool, int dpool_pitch, aau_bf16* dz, int dz_pitch,
                                  const float* scale, const float* shift, const float* save_mean,
                                  const float* save_invstd, float* red, int N, int H, int W, int C, int relu,
-                                 float drop_p, const uint64_t* drop_seed, void* stream) {
-    AAU_REQUIRE(z && scale && shift && save_mean && save_invstd && red, "aau_bn_bwd_reduce: null pointer");
+                                 float drop_p, const uint64_t* drop_seed, float* ws, void* stream) {
+    AAU_REQUIRE(z && scale && shift && save_mean && save_invstd && red && ws, "aau_bn_bwd_reduce: null pointer");
+    AAU_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)red & 15) == 0, "aau_bn_bwd_reduce: red / ws must be 16-byte aligned");
     AAU_REQUIRE(dz || !dpool, "aau_bn_bwd_reduce: the pooled form must store the masked gradient (dz != NULL)");
     AAU_REQUIRE(dy || dpool, "aau_bn_bwd_reduce: needs at least one gradient source");
     CHK_C("aau_bn_bwd_reduce", C);
@@ -590,7 +629,8 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
         if (next_traversal()) ipb = -ipb;
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
                            z_pitch, dy, dy_pitch, dpool, dpool_pitch, dz, dz_pitch, scale, shift, save_mean,
-                           save_invstd, red, N, H, W, C, relu, drop_p, drop_seed, ipb);
+                           save_invstd, red, N, H, W, C, relu, drop_p, drop_seed, ipb, ws);
+        red_fold_launch(ws, 2 * C, (int)blocks, red, 2 * C, nullptr, 0, nullptr, (hipStream_t)stream);
     } else {
         const int64_t items = (int64_t)N * H * W;
         int64_t blocks = (items + mp.PL * 8 - 1) / (mp.PL * 8);
@@ -602,7 +642,8 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
         if (next_traversal()) ipb = -ipb;
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z,
                            z_pitch, dy, dy_pitch, dpool, dpool_pitch, dz, dz_pitch, scale, shift, save_mean,
-                           save_invstd, red, N, H, W, C, relu, drop_p, drop_seed, ipb);
+                           save_invstd, red, N, H, W, C, relu, drop_p, drop_seed, ipb, ws);
+        red_fold_launch(ws, 2 * C, (int)blocks, red, 2 * C, nullptr, 0, nullptr, (hipStream_t)stream);
     }
     return check_launch("aau_bn_bwd_reduce");
 }

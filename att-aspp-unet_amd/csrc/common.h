@@ -149,6 +149,18 @@ __device__ __forceinline__ void stats_publish(const float* sst, int nwaves, int 
     }
 }
 
+// ---- deterministic sums over the workgroups of a launch (BatchNorm backward, the head's parameter gradients) -------
+// Every workgroup stores its row of n partial sums (n % 4 == 0) with plain stores into ws [nblk][n]; red_fold_launch
+// (the kernel boundary is the only synchronisation) then adds the rows in row order and hands the totals out.  The
+// order of the additions depends on the grid only: bitwise reproducible, no float atomics (the fp32-atomic form cost
+// ~1.5 M atomics per deep-layer launch = its whole 30-us floor; an in-kernel last-arriver tree was tried and cost
+// 20-120 us per launch: every workgroup's agent-scope release writes back the whole L2, dz stream included).
+constexpr int AAU_BN_RED_MAX_BLOCKS = 2048;       // grid cap of every launch that writes rows (sizes aau_bn_red_ws_bytes)
+__host__ __device__ inline size_t red_ws_floats(int n, int nblk) { return (size_t)nblk * n; }
+__device__ __forceinline__ float* red_row(float* ws, int n, int blk) { return ws + (size_t)blk * n; }
+// out[0 .. n_out) = totals (overwritten); acc[i] += total[n_out + i] for i < n_acc; acc2[0] += total[n_out + n_acc]
+int red_fold_launch(const float* ws, int n, int nblk, float* out, int n_out, float* acc, int n_acc, float* acc2, hipStream_t s);
+
 // Flat index -> coordinates with 32-bit unsigned division (indices stay below 2^31; the int64 form of % and / costs
 // on the order of a hundred VALU instructions per pixel and showed up as 30-40 % of the pooled BN kernels).
 __device__ __forceinline__ void decode3(int64_t i, int W, int H, int& x, int& y, int& n) {
@@ -191,16 +203,6 @@ struct ProfScope {  // brackets one launch with events when profiling is on
     ~ProfScope();
     int idx;
     hipStream_t stream;
-};
-
-// BatchNorm-backward reduce fused into a data-gradient epilogue (conv3x3.hip, C3Args)
-struct BnRedArgs {
-    const unsigned short* z;
-    int zp;
-    const float* scale;
-    const float* shift;
-    const float* mean;
-    const float* invstd;
 };
 
 // split-K reduction shared by wgrad.hip / wgrad3x3.hip (kernel in wgrad.hip)

@@ -29,15 +29,6 @@ struct C3Args {
     const float* scale;
     const float* shift;
     float* stats;
-    // BatchNorm-backward reduce of the layer that PRODUCED this conv's input, fused into the data-gradient
-    // epilogue (bn_z != null): stats[r][0][c] += sum g, stats[r][1][c] += sum g * zhat with
-    // g = [bn_z*bn_scale+bn_shift > 0] * bf16(dst), zhat = (bn_z - bn_mean) * bn_invstd   (= aau_bn_bwd_reduce)
-    const unsigned short* bn_z;
-    int bn_zp;
-    const float* bn_scale;
-    const float* bn_shift;
-    const float* bn_mean;
-    const float* bn_invstd;
     int rev;             // 1: walk the patches from the end (aau_traverse)
     int nchunk;          // Cpad / 32
     unsigned src_bytes, wpk_bytes;
@@ -46,25 +37,10 @@ struct C3Args {
 
 __device__ __forceinline__ int swz32(int row, int lc) { return lc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
 
-// epilogue statistics of one accumulator quad (4 consecutive channels q.. of one pixel): forward = (sum v, sum v^2);
-// fused BatchNorm-backward reduce = (sum g, sum g*zhat), see C3Args
-__device__ __forceinline__ void epi_stats(const C3Args& a, int64_t pixel, int q, const float v[4], float s1[4], float s2[4]) {
-    if (a.bn_z) {
-        const u32x2 zq = *(const u32x2*)(a.bn_z + pixel * a.bn_zp + q);
-        const float z[4] = {__uint_as_float(zq[0] << 16), __uint_as_float(zq[0] & 0xffff0000u),
-                            __uint_as_float(zq[1] << 16), __uint_as_float(zq[1] & 0xffff0000u)};
-        const f32x4 sc = *(const f32x4*)(a.bn_scale + q), sh = *(const f32x4*)(a.bn_shift + q);
-        const f32x4 mu = *(const f32x4*)(a.bn_mean + q), is = *(const f32x4*)(a.bn_invstd + q);
+// epilogue statistics of one accumulator quad (4 consecutive channels q.. of one pixel): (sum v, sum v^2)
+__device__ __forceinline__ void epi_stats(const C3Args&, int64_t, int, const float v[4], float s1[4], float s2[4]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float g = (z[r] * sc[r] + sh[r] > 0.f) ? bf2f(f2bf(v[r])) : 0.f;
-            s1[r] += g;
-            s2[r] += g * ((z[r] - mu[r]) * is[r]);
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
-    }
+    for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
 }
 
 // s_waitcnt takes an immediate; the pipeline below only ever needs these four counts per tile shape
@@ -344,17 +320,7 @@ __global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
             }
         }
         __syncthreads();
-        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
-            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-            if (tid < 2 * BQ) {
-                const int which = tid / BQ, ql = tid - which * BQ;
-                float v = 0.f;
-                for (int w = 0; w < NWAVE; ++w) v += sst[w * 2 * BQ + tid];
-                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
-            }
-        } else {
-            stats_publish(sst, NWAVE, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
-        }
+        stats_publish(sst, NWAVE, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 #ifdef ABL_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -584,17 +550,7 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
             }
         }
         __syncthreads();
-        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
-            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-            if (tid < 2 * BQ) {
-                const int which = tid / BQ, ql = tid - which * BQ;
-                float v = 0.f;
-                for (int w = 0; w < 4; ++w) v += sst[w * 2 * BQ + tid];
-                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
-            }
-        } else {
-            stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
-        }
+        stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -860,17 +816,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
             }
         }
         __syncthreads();
-        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
-            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-            if (tid < 2 * BQ) {
-                const int which = tid / BQ, ql = tid - which * BQ;
-                float v = 0.f;
-                for (int w = 0; w < 4; ++w) v += sst[w * 2 * BQ + tid];
-                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
-            }
-        } else {
-            stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
-        }
+        stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -1111,17 +1057,7 @@ __global__ __launch_bounds__(320) void conv3x3l_kernel(const C3Args a) {
             }
         }
         __syncthreads();
-        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
-            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-            if (tid < 2 * BQ) {
-                const int which = tid / BQ, ql = tid - which * BQ;
-                float v = 0.f;
-                for (int w = 0; w < 5; ++w) v += sst[w * 2 * BQ + tid];
-                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
-            }
-        } else {
-            stats_publish(sst, 5, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
-        }
+        stats_publish(sst, 5, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -1322,17 +1258,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
             }
         }
         __syncthreads();
-        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
-            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-            if (tid < 2 * BQ) {
-                const int which = tid / BQ, ql = tid - which * BQ;
-                float v = 0.f;
-                for (int w = 0; w < NW; ++w) v += sst[w * 2 * BQ + tid];
-                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
-            }
-        } else {
-            stats_publish(sst, NW, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
-        }
+        stats_publish(sst, NW, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -1528,17 +1454,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
             }
         }
         __syncthreads();
-        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
-            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-            if (tid < 2 * BQ) {
-                const int which = tid / BQ, ql = tid - which * BQ;
-                float v = 0.f;
-                for (int w = 0; w < 8; ++w) v += sst[w * 2 * BQ + tid];
-                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
-            }
-        } else {
-            stats_publish(sst, 8, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
-        }
+        stats_publish(sst, 8, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -1757,17 +1673,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             }
         }
         __syncthreads();
-        if (a.bn_z) {   // fused BatchNorm-backward reduce (opt-in): fp32 replicas that aau_bn_bwd_apply folds
-            float* st = a.stats + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * d.Cout;
-            if (tid < 2 * BQ) {
-                const int which = tid / BQ, ql = tid - which * BQ;
-                float v = 0.f;
-                for (int w = 0; w < NW; ++w) v += sst[w * 2 * BQ + tid];
-                if (q0 + ql < d.Cout) atomicAdd(st + which * d.Cout + q0 + ql, v);
-            }
-        } else {
-            stats_publish(sst, NW, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
-        }
+        stats_publish(sst, NW, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -1795,7 +1701,6 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     C3Args a;
     a.d = *d;
     a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
-    a.bn_z = nullptr; a.bn_zp = 0; a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr;
     a.rev = next_traversal();
     a.nchunk = d->Cpad / 32;
     a.src_bytes = src_bytes;
@@ -1832,14 +1737,10 @@ bool conv3x3_applicable(const aau_conv_desc* d) {
 
 int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
                    const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
-                   const BnRedArgs* bn, hipStream_t s) {
+                   hipStream_t s) {
     C3Args a;
     a.d = *d;
     a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
-    a.bn_z = bn ? bn->z : nullptr;
-    a.bn_zp = bn ? bn->zp : 0;
-    a.bn_scale = bn ? bn->scale : nullptr; a.bn_shift = bn ? bn->shift : nullptr;
-    a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr;
     a.rev = next_traversal();
     a.nchunk = d->Cpad / 32;
     a.src_bytes = src_bytes;

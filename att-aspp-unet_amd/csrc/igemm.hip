@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 bool conv3x3_applicable(const aau_conv_desc* d);
 int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
                    const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
-                   const BnRedArgs* bn, hipStream_t s);
+                   hipStream_t s);
 
 bool conv1x1_resw_applicable(const aau_conv_desc* d, bool want_stats);
 int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
@@ -387,8 +387,7 @@ static int launch(const IgemmArgs& a, hipStream_t s) {
 }  // namespace aau
 
 static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst,
-                         const float* bias, const float* scale, const float* shift, float* stats,
-                         const aau::BnRedArgs* bn, void* stream) {
+                         const float* bias, const float* scale, const float* shift, float* stats, void* stream) {
     using namespace aau;
     AAU_REQUIRE(d && src && wpk && dst, "aau_conv_igemm: null pointer");
     AAU_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0, "aau_conv_igemm: Cin=%d must be a positive multiple of 8", d->Cin);
@@ -427,9 +426,7 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
                              (double)d->Cout * d->KH * d->KW * d->Cin));
     a.rev = 0;
     if (conv3x3_applicable(d))
-        return conv3x3_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, bn,
-                              (hipStream_t)stream);
-    AAU_REQUIRE(!bn, "aau_conv_igemm_bnred: only the halo-tiled 3x3 path carries the fused reduce (aau_conv_is_halo3x3)");
+        return conv3x3_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, (hipStream_t)stream);
     if (conv1x1_resw_applicable(d, stats != nullptr))
         return conv1x1_resw_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, (hipStream_t)stream);
     a.rev = next_traversal();
@@ -444,20 +441,9 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
 extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
                               aau_bf16* dst, const float* bias, const float* scale, const float* shift,
                               aau_stat* stats, void* stream) {
-    return conv_dispatch(d, src, wpk, dst, bias, scale, shift, (float*)stats, nullptr, stream);
+    return conv_dispatch(d, src, wpk, dst, bias, scale, shift, (float*)stats, stream);
 }
 
 extern "C" int aau_conv_is_halo3x3(const aau_conv_desc* d) {
     return d && aau::conv3x3_applicable(d) && !d->accumulate ? 1 : 0;
-}
-
-extern "C" int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst,
-                                    const aau_bf16* bn_z, int bn_z_pitch, const float* bn_scale, const float* bn_shift,
-                                    const float* bn_mean, const float* bn_invstd, float* red, void* stream) {
-    using namespace aau;
-    AAU_REQUIRE(d && bn_z && bn_scale && bn_shift && bn_mean && bn_invstd && red, "aau_conv_igemm_bnred: null pointer");
-    AAU_REQUIRE(aau_conv_is_halo3x3(d), "aau_conv_igemm_bnred: needs a 3x3 / pad 1 / stride 1 conv on a 16-aligned grid, no accumulate");
-    AAU_REQUIRE(bn_z_pitch % 4 == 0 && d->Cout % 4 == 0 && ((uintptr_t)bn_z & 7) == 0, "aau_conv_igemm_bnred: z pitch / alignment");
-    BnRedArgs bn{bn_z, bn_z_pitch, bn_scale, bn_shift, bn_mean, bn_invstd};
-    return conv_dispatch(d, src, wpk, dst, nullptr, nullptr, nullptr, red, &bn, stream);
 }

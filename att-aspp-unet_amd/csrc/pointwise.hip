@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void conv1_bn_act_kernel(const float* x, const
 __global__ __launch_bounds__(256) void conv1_bn_bwd_reduce_kernel(const float* x, const float* w, const unsigned short* dy,
                                                                   int dyp, const float* scale, const float* shift,
                                                                   const float* mean, const float* invstd, float* red,
-                                                                  int N, int H, int W, int C, int64_t ppb) {
+                                                                  int N, int H, int W, int C, int64_t ppb, float* ws) {
     extern __shared__ float sm[];  // [C*9] weights, then [256*8] reduction scratch
     float* sw = sm;
     float* sred = sm + C * 9;
@@ -153,16 +153,17 @@ __global__ __launch_bounds__(256) void conv1_bn_bwd_reduce_kernel(const float* x
             }
         }
     }
-    float* r = red + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2 * C;
+    // this workgroup's row; red_fold_launch adds the rows in a fixed order (common.h), totals into red [2][C]
+    float* r = red_row(ws, 2 * C, blockIdx.x);
     block_sum8b(s1, sred, mp, tid);
     if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s1[j]);
+        *(f32x4*)(r + c) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+        *(f32x4*)(r + c + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
     }
     block_sum8b(s2, sred, mp, tid);
     if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
+        *(f32x4*)(r + C + c) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+        *(f32x4*)(r + C + c + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
     }
 }
 
@@ -329,8 +330,8 @@ __global__ __launch_bounds__(256) void bn_act_outconv_wave_kernel(const unsigned
 
 // ---- network head, backward: the gradient w.r.t. the last activation is rank one (dlogits[m] * w[c]), so it is
 // never materialised either.  This pass = outconv_bwd (dw += sum dl*y, db += sum dl, y recomputed from z) +
-// bn_bwd_reduce of the last BatchNorm (g = [y>0] * bf16(dl*w), sums of g and g*zhat).  ws: [R][C+8] replicas of
-// (dw, db), zeroed by the caller of the kernel; red: [R][2][C].
+// bn_bwd_reduce of the last BatchNorm (g = [y>0] * bf16(dl*w), sums of g and g*zhat).  One row [s1 C][s2 C][dw C][db 8]
+// per workgroup, summed over workgroups in a fixed order (common.h: red_fold_launch): red [2][C] = totals, dw / db +=.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_outconv_kernel(const unsigned short* z, int zp, const float* dl,
                                                                     const float* w, const float* scale,
                                                                     const float* shift, const float* mean,
@@ -364,26 +365,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_outconv_kernel(const unsign
             if (cg == 0) sb[0] += g;
         }
     }
-    const int rep = blockIdx.x % AAU_STAT_REPLICAS;
-    float* r = red + (size_t)rep * 2 * C;
-    float* ro = ws + (size_t)rep * (C + 8);
+    const int n = 3 * C + 8;
+    float* r = red_row(ws, n, blockIdx.x);
     block_sum8b(s1, sred, mp, tid);
     if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(r + c + j, s1[j]);
+        *(f32x4*)(r + c) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+        *(f32x4*)(r + c + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
     }
     block_sum8b(s2, sred, mp, tid);
     if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(r + C + c + j, s2[j]);
+        *(f32x4*)(r + C + c) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+        *(f32x4*)(r + C + c + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
     }
     block_sum8b(sw, sred, mp, tid);
     if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(ro + c + j, sw[j]);
+        *(f32x4*)(r + 2 * C + c) = f32x4{sw[0], sw[1], sw[2], sw[3]};
+        *(f32x4*)(r + 2 * C + c + 4) = f32x4{sw[4], sw[5], sw[6], sw[7]};
     }
     block_sum8b(sb, sred, mp, tid);
-    if (tid == 0) atomicAdd(ro + C, sb[0]);
+    if (tid == 0) {
+        *(f32x4*)(r + 3 * C) = f32x4{sb[0], 0.f, 0.f, 0.f};
+        *(f32x4*)(r + 3 * C + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 // out[i] += sum over replicas of ws[r][i] (i < n); optionally a second target for element n (bias)
@@ -778,6 +781,7 @@ extern "C" int aau_bn_bwd_reduce_outconv(const aau_bf16* z, int z_pitch, const f
                                          int C, void* stream) {
     AAU_REQUIRE(z && dlogits && w && scale && shift && save_mean && save_invstd && red && dw && ws && M > 0,
                 "aau_bn_bwd_reduce_outconv: bad args");
+    AAU_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)red & 15) == 0, "aau_bn_bwd_reduce_outconv: red / ws must be 16-byte aligned");
     CHK_C("aau_bn_bwd_reduce_outconv", C);
     AAU_REQUIRE(z_pitch % 8 == 0, "aau_bn_bwd_reduce_outconv: pitch");
     const CGMap2 mp(C);
@@ -785,11 +789,9 @@ extern "C" int aau_bn_bwd_reduce_outconv(const aau_bf16* z, int z_pitch, const f
     split_rows(M, mp.PL, 16, 2048, &blocks, &ppb);
     if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 8.0 * M * C, (hipStream_t)stream);
-    zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * (C + 8), (hipStream_t)stream);
     hipLaunchKernelGGL(bn_bwd_reduce_outconv_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, z_pitch,
                        dlogits, w, scale, shift, save_mean, save_invstd, red, ws, M, C, ppb);
-    hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 256) / 256), dim3(256), 0, (hipStream_t)stream, ws, C + 8, dw, C,
-                       db);
+    red_fold_launch(ws, 3 * C + 8, (int)blocks, red, 2 * C, dw, C, db, (hipStream_t)stream);
     return check_launch("aau_bn_bwd_reduce_outconv");
 }
 
@@ -811,9 +813,11 @@ extern "C" int aau_conv1_bn_act(const float* x, const float* w, aau_bf16* y, int
 
 extern "C" int aau_conv1_bn_bwd_reduce(const float* x, const float* w, const aau_bf16* dy, int dy_pitch,
                                        const float* scale, const float* shift, const float* save_mean,
-                                       const float* save_invstd, float* red, int N, int H, int W, int C, void* stream) {
-    AAU_REQUIRE(x && w && dy && scale && shift && save_mean && save_invstd && red && N > 0 && H > 0 && W > 0,
+                                       const float* save_invstd, float* red, int N, int H, int W, int C, float* ws,
+                                       void* stream) {
+    AAU_REQUIRE(x && w && dy && scale && shift && save_mean && save_invstd && red && ws && N > 0 && H > 0 && W > 0,
                 "aau_conv1_bn_bwd_reduce: bad args");
+    AAU_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)red & 15) == 0, "aau_conv1_bn_bwd_reduce: red / ws must be 16-byte aligned");
     CHK_C("aau_conv1_bn_bwd_reduce", C);
     AAU_REQUIRE(dy_pitch % 8 == 0, "aau_conv1_bn_bwd_reduce: pitch");
     AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_conv1_bn_bwd_reduce: pixel count overflows int32");
@@ -823,6 +827,7 @@ extern "C" int aau_conv1_bn_bwd_reduce(const float* x, const float* w, const aau
     if (next_traversal()) ppb = -ppb;
     ProfScope prof(2, 2.0 * N * H * W * 9.0 * C, (hipStream_t)stream);
     hipLaunchKernelGGL(conv1_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (C * 9 + 256 * 8) * sizeof(float),
-                       (hipStream_t)stream, x, w, dy, dy_pitch, scale, shift, save_mean, save_invstd, red, N, H, W, C, ppb);
+                       (hipStream_t)stream, x, w, dy, dy_pitch, scale, shift, save_mean, save_invstd, red, N, H, W, C, ppb, ws);
+    red_fold_launch(ws, 2 * C, (int)blocks, red, 2 * C, nullptr, 0, nullptr, (hipStream_t)stream);
     return check_launch("aau_conv1_bn_bwd_reduce");
 }

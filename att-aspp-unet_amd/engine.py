@@ -341,6 +341,10 @@ class Plan:
                                    dtype=torch.int64) if train else None     # channel sums of dcat (4 levels x 3*Co)
         self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3 + STAT_REPLICAS * nbn * 3, self.dev)
         self.vec_arena = _Arena(nbn * 8 + 64, self.dev)
+        # workspace of the fixed-order cross-workgroup sums of the BatchNorm-backward reduce passes (include/aau.h:
+        # aau_bn_red_ws_bytes): shared by all layers (reduce -> apply are adjacent on the stream)
+        self.red_ws = torch.zeros(ops.bn_red_ws_bytes(max(b.C for b in st.bns.values())) // 4, dtype=F32,
+                                  device=self.dev) if train else None
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
         self.logits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev)
         self.dlogits = torch.zeros(B, 1, H, W, dtype=F32, device=self.dev) if train else None
@@ -409,10 +413,8 @@ class Plan:
         return rec
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
-    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, feeds=None, din_stats=None,
+    def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, din_stats=None,
                 defer_wgrad=None):
-        """``feeds``: record of the ConvBNReLU whose output is this layer's ONLY consumer input (din is its full
-        output gradient): its BatchNorm-backward reduce is then fused into this layer's data-gradient epilogue."""
         cv, bn, w = r["cv"], r["bn"], r["w"]
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
@@ -424,18 +426,17 @@ class Plan:
         if head is not None:
             # network head: dy = dlogits x w_out is rank one and never stored (see cbr_fwd)
             b.add("aau_bn_bwd_reduce_outconv", r["z"], cv.O, self.dlogits, head.w, w["scale"], w["shift"], w["mean"],
-                  w["invstd"], w["red"], head.dw, head.dbias, self.rep_ws, M, cv.O)
+                  w["invstd"], w["red"], head.dw, head.dbias, self.red_ws, M, cv.O)
             b.add("aau_bn_bwd_apply_rank1", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
                   bn.dbeta, M, cv.O, self.dlogits, head.w, w["scale"], w["shift"])
         elif dpool is None:
             # no pooling: the reduce pass only accumulates, the apply pass recomputes the ReLU / dropout mask
-            if not r.get("reduced_by_consumer", False):
-                if r["z"] is None:      # first layer, z not stored
-                    b.add("aau_conv1_bn_bwd_reduce", r["src"], cv.w, dy, dyp, w["scale"], w["shift"], w["mean"],
-                          w["invstd"], w["red"], N, H, W, cv.O)
-                else:
-                    b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"],
-                          w["mean"], w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
+            if r["z"] is None:      # first layer, z not stored
+                b.add("aau_conv1_bn_bwd_reduce", r["src"], cv.w, dy, dyp, w["scale"], w["shift"], w["mean"],
+                      w["invstd"], w["red"], N, H, W, cv.O, self.red_ws)
+            else:
+                b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, None, 0, None, cv.O, w["scale"], w["shift"],
+                      w["mean"], w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed, self.red_ws)
             if fuse1:
                 # first layer: no input gradient, so the apply pass feeds the weight gradient directly
                 b.add("aau_bn_bwd_apply_conv1", r["z"], cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
@@ -445,7 +446,7 @@ class Plan:
                   bn.dbeta, M, cv.O, dy, dyp, w["scale"], w["shift"], 1, dp_, self.drop_seed)
         else:
             b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, dpool, dpp, dz, cv.O, w["scale"], w["shift"], w["mean"],
-                  w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed)
+                  w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed, self.red_ws)
             b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
                   bn.dbeta, M, cv.O, None, 0, None, None, 1, 0.0, self.drop_seed)
         pad = cv.dil * (cv.k // 2)
@@ -463,16 +464,8 @@ class Plan:
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate)
-            if (feeds is not None and feeds["z"] is not None and not self.eng.no_fuse_bnred and not feeds["drop"]
-                    and dinp == feeds["cv"].O
-                    and ops.conv_is_halo3x3(dd)):
-                fw = feeds["w"]
-                b.add("aau_conv_igemm_bnred", dd, dz, cv.pk_d, din, feeds["z"], feeds["cv"].O, fw["scale"], fw["shift"],
-                      fw["mean"], fw["invstd"], fw["red"])
-                feeds["reduced_by_consumer"] = True
-            else:
-                # din_stats: [R][2][Cin] sums of the produced gradient (channel sums feed the ConvTranspose bias grad)
-                b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, din_stats)
+            # din_stats: [R][2][Cin] sums of the produced gradient (channel sums feed the ConvTranspose bias grad)
+            b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, din_stats)
         return dz
 
     # ---- graph ----
@@ -650,7 +643,7 @@ class Plan:
         for blk in reversed(dec):            # u1, u2, u3, u4
             lv, Co, Mo, ho, wo, hi, wi = blk["lv"], blk["Co"], blk["Mo"], blk["ho"], blk["wo"], blk["hi"], blk["wi"]
             dya = self.new(Mo, Co)
-            self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co, feeds=blk["ra"])
+            self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co)
             dcat = self.new(Mo, 2 * Co)
             # channel sums of dcat (fp32, from the data-gradient epilogue) -> ConvTranspose2d bias gradient below
             sA = None if eng.no_fuse_colsum else self.bstats_arena.take(ops.stat_words(2 * Co))
@@ -759,7 +752,7 @@ class Plan:
             ra, rb = enc[lv]
             dsk, dskp = dskip[lv], dskip_p[lv]
             dya = self.new(Ms[lv], Cs[lv])
-            self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv], feeds=ra)
+            self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv])
             if lv > 0:
                 dprev = self.new(Ms[lv], Cs[lv - 1])
                 self.cbr_bwd(ra, dya, Cs[lv], din=dprev, dinp=Cs[lv - 1])
@@ -833,9 +826,6 @@ class Engine:
         # z of the first layer recomputed from the frame instead of stored (-201 MB of HBM at bs 8 / 512^2): measured
         # 0.08 ms SLOWER per step (the three recomputing kernels are VALU / latency bound, not byte bound), so opt-in
         self.no_recompute_z1 = os.environ.get("AAU_RECOMPUTE_Z1", "0") != "1" or self.no_fuse_conv1
-        # BN-backward reduce inside the consumer's data-gradient epilogue (aau_conv_igemm_bnred): measured a wash
-        # (elementwise -0.41 ms, conv +0.43 ms per step: the epilogue's extra z read is not hidden), so opt-in
-        self.no_fuse_bnred = os.environ.get("AAU_FUSE_BNRED", "0") != "1"
 
     def dropout_p(self) -> float:
         """p of the bridge's Dropout: ASPP.project[3] (pipeline:78) or Sequential(ConvBNReLU, Dropout)[1] (ablation:196)."""

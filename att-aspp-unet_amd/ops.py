@@ -88,11 +88,6 @@ def conv_is_halo3x3(desc: ConvDesc) -> bool:
     return bool(fn("aau_conv_is_halo3x3")(C.byref(desc)))
 
 
-def conv_igemm_bnred(desc: ConvDesc, src, wpk, dst, bn_z, bn_zp, bn_scale, bn_shift, bn_mean, bn_invstd, red):
-    check(fn("aau_conv_igemm_bnred")(C.byref(desc), _p(src), _p(wpk), _p(dst), _p(bn_z), bn_zp, _p(bn_scale),
-                                     _p(bn_shift), _p(bn_mean), _p(bn_invstd), _p(red), _stream()), "aau_conv_igemm_bnred")
-
-
 def conv_wgrad_ws_bytes(desc: ConvDesc) -> int:
     n = C.c_int64(0)
     check(fn("aau_conv_wgrad_ws_bytes")(C.byref(desc), C.byref(n)), "aau_conv_wgrad_ws_bytes")
@@ -166,11 +161,31 @@ def maxpool2(y, yp, p, pp, N, H, W, Cc):
     check(fn("aau_maxpool2")(_p(y), yp, _p(p), pp, N, H, W, Cc, _stream()), "aau_maxpool2")
 
 
+def bn_red_ws_bytes(Cc: int) -> int:
+    """Bytes of the reusable workspace of the BatchNorm-backward reduce passes for <= Cc channels."""
+    return int(_abi.lib().aau_bn_red_ws_bytes(int(Cc)))
+
+
+_red_ws = {}
+
+
+def bn_red_ws(Cc: int, device):
+    """A process-wide workspace for eager calls (one per device, grown on demand)."""
+    need = bn_red_ws_bytes(Cc) // 4
+    ws = _red_ws.get(str(device))
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.float32, device=device)
+        _red_ws[str(device)] = ws
+    return ws
+
+
 def bn_bwd_reduce(z, zp, dy, dyp, dpool, dpp, dz, dzp, scale, shift, smean, sinvstd, red, N, H, W, Cc,
-                  relu=1, drop_p=0.0, drop_seed=0):
+                  relu=1, drop_p=0.0, drop_seed=0, ws=None):
+    """red: fp32 [2][C], overwritten with the totals (sum g, sum g*zhat)."""
     sp, _keep = _seed_ptr(drop_seed, drop_p)
+    ws = bn_red_ws(Cc, red.device) if ws is None else ws
     check(fn("aau_bn_bwd_reduce")(_p(z), zp, _p(dy), dyp, _p(dpool), dpp, _p(dz), dzp, _p(scale), _p(shift),
-                                  _p(smean), _p(sinvstd), _p(red), N, H, W, Cc, relu, drop_p, sp,
+                                  _p(smean), _p(sinvstd), _p(red), N, H, W, Cc, relu, drop_p, sp, _p(ws),
                                   _stream()), "aau_bn_bwd_reduce")
 
 
@@ -194,9 +209,10 @@ def conv1_bn_act(x, w, y, yp, scale, shift, N, H, W, Cc):
     check(fn("aau_conv1_bn_act")(_p(x), _p(w), _p(y), yp, _p(scale), _p(shift), N, H, W, Cc, _stream()), "aau_conv1_bn_act")
 
 
-def conv1_bn_bwd_reduce(x, w, dy, dyp, scale, shift, smean, sinvstd, red, N, H, W, Cc):
+def conv1_bn_bwd_reduce(x, w, dy, dyp, scale, shift, smean, sinvstd, red, N, H, W, Cc, ws=None):
+    ws = bn_red_ws(Cc, red.device) if ws is None else ws
     check(fn("aau_conv1_bn_bwd_reduce")(_p(x), _p(w), _p(dy), dyp, _p(scale), _p(shift), _p(smean), _p(sinvstd), _p(red),
-                                        N, H, W, Cc, _stream()), "aau_conv1_bn_bwd_reduce")
+                                        N, H, W, Cc, _p(ws), _stream()), "aau_conv1_bn_bwd_reduce")
 
 
 def gap_fwd(x, xp, pooled, ws, N, HW, Cc):
@@ -256,6 +272,9 @@ def bn_act_outconv(z, zp, scale, shift, w, b, logits, M, Cc):
 
 
 def bn_bwd_reduce_outconv(z, zp, dlogits, w, scale, shift, smean, sinvstd, red, dw, db, ws, M, Cc):
+    ws = bn_red_ws(Cc, red.device) if ws is None else ws
+    if ws.numel() * ws.element_size() < bn_red_ws_bytes(Cc):
+        raise _abi.AauError(f"bn_bwd_reduce_outconv: workspace of {ws.numel() * ws.element_size()} B, need {bn_red_ws_bytes(Cc)} B")
     check(fn("aau_bn_bwd_reduce_outconv")(_p(z), zp, _p(dlogits), _p(w), _p(scale), _p(shift), _p(smean), _p(sinvstd),
                                           _p(red), _p(dw), _p(db), _p(ws), M, Cc, _stream()), "aau_bn_bwd_reduce_outconv")
 

@@ -104,18 +104,9 @@ int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    aau_bf16* dst, const float* bias, const float* scale, const float* shift,
                    aau_stat* stats, void* stream);
 
-/* Data-gradient conv (3x3, pad 1, stride 1, H and W multiples of 16: aau_conv_is_halo3x3)  */
-/* with the BatchNorm-backward REDUCE of the layer that produced the conv's input fused    */
-/* into the epilogue: dst = the gradient w.r.t. that layer's output y = relu(bn(z)), and    */
-/* red[r][0][c] += sum g, red[r][1][c] += sum g*zhat with g = [bn_z*bn_scale+bn_shift > 0]  */
-/* * bf16(dst), zhat = (bn_z - bn_mean)*bn_invstd -- exactly what aau_bn_bwd_reduce(dz=NULL) */
-/* would accumulate from dst; aau_bn_bwd_apply(dy = dst, ...) follows.  Saves one read of   */
-/* dst and one launch per ConvBNReLU whose output feeds a single 3x3 conv.                  */
+/* 1 when the halo-tiled 3x3 kernels (csrc/conv3x3.hip) serve this descriptor: 3x3, pad 1,   */
+/* stride 1, H and W multiples of 16, no accumulate.                                         */
 int aau_conv_is_halo3x3(const aau_conv_desc* d);
-int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
-                         aau_bf16* dst, const aau_bf16* bn_z, int bn_z_pitch,
-                         const float* bn_scale, const float* bn_shift, const float* bn_mean,
-                         const float* bn_invstd, float* red, void* stream);
 
 /* Weight-gradient of the same convolutions (ATen convolution_backward, weight part):   */
 /* dw[q][t][c] += sum_m dz[m][q] * src[gather(m,t)][c]   (the caller zeroes dw)         */
@@ -205,13 +196,20 @@ int aau_maxpool2(const aau_bf16* y, int y_pitch, aau_bf16* p, int p_pitch, int N
 /*   dy (same resolution, optional) and dpool (gradient of MaxPool2d(2) output, optional, */
 /*   routed to the first maximum of each window).  Pass 1 writes the masked gradient      */
 /*   g = relu'(y) * (dy + pool-routed) into dz and accumulates sum(g), sum(g*zhat) into    */
-/*   red [AAU_STAT_REPLICAS][2][C]; pass 2 turns it into dz in place and adds dgamma /     */
-/*   dbeta.                                                                              */
+/*   red [2][C] (overwritten: totals over all pixels); pass 2 turns it into dz in place    */
+/*   and adds dgamma / dbeta.                                                            */
 int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16* dy, int dy_pitch,
                       const aau_bf16* dpool, int dpool_pitch, aau_bf16* dz, int dz_pitch,
                       const float* scale, const float* shift, const float* save_mean,
                       const float* save_invstd, float* red, int N, int H, int W, int C,
-                      int relu, float drop_p, const uint64_t* drop_seed, void* stream);
+                      int relu, float drop_p, const uint64_t* drop_seed, float* ws, void* stream);
+/* Workspace of the reduce passes (aau_bn_bwd_reduce, aau_conv1_bn_bwd_reduce,                */
+/* aau_bn_bwd_reduce_outconv) for a BatchNorm of up to C channels: every workgroup stores    */
+/* its row of partial sums there and a second launch adds the rows in an order that depends  */
+/* on the grid only (no float atomics: bitwise reproducible).  16-byte aligned, contents     */
+/* irrelevant on entry; one buffer serves any number of calls issued one after another on a  */
+/* stream (never two at the same time).                                                      */
+int64_t aau_bn_red_ws_bytes(int C);
 /* Non-pooled layers may skip the intermediate: pass dz = NULL to the reduce pass and give */
 /* the apply pass dy (+ scale, shift, relu, dropout parameters); it recomputes the mask.   */
 int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
@@ -238,7 +236,7 @@ int aau_conv1_bn_act(const float* x, const float* w, aau_bf16* y, int y_pitch, c
 int aau_conv1_bn_bwd_reduce(const float* x, const float* w, const aau_bf16* dy, int dy_pitch,
                             const float* scale, const float* shift, const float* save_mean,
                             const float* save_invstd, float* red, int N, int H, int W, int C,
-                            void* stream);
+                            float* ws, void* stream);
 
 /* ---- ASPP image-pool branch (pipeline:75-77,82) -------------------------------------- */
 /* ws: caller-provided fp32 [N*C] workspace (zeroed by the call)                        */
@@ -300,8 +298,7 @@ int aau_bn_act_outconv(const aau_bf16* z, int z_pitch, const float* scale, const
 /* backward: the gradient w.r.t. that activation is rank one, dy[m][c] = bf16(dlogits[m]*w[c]),   */
 /* and is never written either.  reduce_outconv = aau_outconv_bwd's parameter gradients           */
 /* (dw[c] += sum dl*y, db += sum dl; y recomputed from z) + aau_bn_bwd_reduce of the last         */
-/* BatchNorm; ws: fp32 [AAU_STAT_REPLICAS][C+8] scratch.  apply_rank1 = aau_bn_bwd_apply with     */
-/* that dy.                                                                                      */
+/* BatchNorm; ws: aau_bn_red_ws_bytes(C).  apply_rank1 = aau_bn_bwd_apply with that dy.            */
 int aau_bn_bwd_reduce_outconv(const aau_bf16* z, int z_pitch, const float* dlogits, const float* w,
                               const float* scale, const float* shift, const float* save_mean,
                               const float* save_invstd, float* red, float* dw, float* db, float* ws,

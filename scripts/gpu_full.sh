@@ -2,7 +2,7 @@
 # full GPU suite + bench line (no CPU baseline) ; usage: gpu_full.sh <tag>
 O=gpurun_out/$1; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -6 $O/pytest.log
-timeout -k 10 300 python bench.py --no-cpu-baseline --no-infer > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-infer --dump-launches $O/launches.txt > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python - <<PY
 import json
 d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])

@@ -460,8 +460,7 @@ def test_network_head_fused_forward_and_backward(ops, C):
     lg1 = zeros(M)
     ops.bn_act_outconv(z, C, scale, shift, w, b, lg1, M, C)
     red1, dw1, db1 = zeros(ops.STAT_REPLICAS, 2, C), zeros(C), zeros(1)
-    ws.fill_(float("nan"))
-    ops.bn_bwd_reduce_outconv(z, C, dl, w, scale, shift, dev(mean), dev(invstd), red1, dw1, db1, ws, M, C)
+    ops.bn_bwd_reduce_outconv(z, C, dl, w, scale, shift, dev(mean), dev(invstd), red1, dw1, db1, None, M, C)
     dz1, dg1, dbt1 = zeros(M, C, dtype=torch.bfloat16), zeros(C), zeros(C)
     ops.bn_bwd_apply_rank1(z, C, dz1, C, dev(gamma), dev(mean), dev(invstd), red1, dg1, dbt1, M, C, dl, w, scale, shift)
     torch.cuda.synchronize()
@@ -511,3 +510,42 @@ def test_first_layer_z_recomputed_instead_of_stored(ops, C):
     assert rel_err(red1.sum(0).cpu(), red0.sum(0).cpu()) < 1e-5
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert rel_err(outs[1][2].cpu(), outs[0][2].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(8, 32, 32, 768), (2, 64, 64, 384), (8, 128, 128, 48), (1, 8, 8, 104), (3, 16, 24, 2048)])
+def test_bn_backward_sums_are_order_independent_and_exact(ops, case):
+    """The reduce pass adds the workgroups' rows in a fixed order (csrc/common.h: red_fold_launch): the totals are
+    bitwise reproducible, equal a float64 reference to fp32 rounding, and one workspace serves launches of different
+    grids one after another (pooled and not) without being cleared."""
+    N, H, W, C = case
+    g = torch.Generator().manual_seed(sum(case))
+    z = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    gy = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    gp = torch.randn(N, H // 2, W // 2, C, generator=g).to(torch.bfloat16)
+    flat = z.float().reshape(-1, C)
+    mean, invstd = flat.mean(0), 1 / torch.sqrt(flat.var(0, unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    zd, gyd, gpd = dev(z), dev(gy), dev(gp)
+    args = (dev(scale), dev(shift), dev(mean), dev(invstd))
+    ws = torch.full((ops.bn_red_ws_bytes(C) // 4,), float("nan"), device="cuda")
+    t = z.double() * scale.double() + shift.double()
+    gm = torch.where(t.float() > 0, gy.double(), torch.zeros((), dtype=torch.float64))     # the mask is taken in fp32
+    zh = (z.double() - mean.double()) * invstd.double()
+    ref = torch.stack([gm.sum((0, 1, 2)), (gm * zh).sum((0, 1, 2))])
+    outs = []
+    for rep in range(3):
+        red = torch.full((2, C), float("nan"), device="cuda")
+        ops.bn_bwd_reduce(zd, C, gyd, C, None, 0, None, C, *args, red, N, H, W, C, relu=1, ws=ws)
+        outs.append(red.clone())
+        # the pooled form on the same workspace in between (a different grid: other group sizes)
+        dz = torch.empty(N, H, W, C, dtype=torch.bfloat16, device="cuda")
+        redp = torch.full((2, C), float("nan"), device="cuda")
+        ops.bn_bwd_reduce(zd, C, gyd, C, gpd, C, dz, C, *args, redp, N, H, W, C, relu=1, ws=ws)
+        outs.append(redp.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[4])
+    assert torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[5])
+    assert not torch.isnan(outs[1]).any()
+    err = (outs[0].double().cpu() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2e-5, float(err)

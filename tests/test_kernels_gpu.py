@@ -227,42 +227,6 @@ def test_igemm_dgrad(ops, case):
     assert rel_err(out.cpu(), ref) < 6e-3
 
 
-# (N, H, W, channels of dz, channels of the produced gradient): grouped-tap kernel <96> / <48>, resident-weight <48> / <96>
-BNRED_CASES = [(2, 32, 32, 96, 96), (2, 32, 48, 96, 40), (4, 256, 256, 48, 48), (4, 256, 256, 48, 96), (8, 256, 256, 48, 48)]
-
-
-@pytest.mark.parametrize("case", BNRED_CASES)
-def test_dgrad_with_fused_bn_backward_reduce(ops, case):
-    """aau_conv_igemm_bnred == aau_conv_igemm followed by aau_bn_bwd_reduce(dz=NULL) on its bf16 output."""
-    N, H, W, Cz, Cy = case
-    g = torch.Generator().manual_seed(sum(case))
-    dz = dev(torch.randn(N, H, W, Cz, generator=g).to(torch.bfloat16))
-    w = R.bf16_round(torch.randn(Cz, Cy, 3, 3, generator=g) / (Cz * 9) ** 0.5)
-    zprev = dev(torch.randn(N, H, W, Cy, generator=g).to(torch.bfloat16))
-    scale, shift = dev(torch.rand(Cy, generator=g) + 0.5), dev(torch.randn(Cy, generator=g) * 0.3)
-    mean, invstd = dev(torch.randn(Cy, generator=g) * 0.1), dev(torch.rand(Cy, generator=g) + 0.5)
-    cpad = ops.cpad_of(Cz)
-    d = ops.conv_desc(N, H, W, Cz, Cz, H, W, Cy, Cy, 3, 3, 1, 1, 1, cpad)
-    assert ops.conv_is_halo3x3(d)
-    wp = dev(pack_dgrad(w, cpad))
-    out0 = torch.empty(N, H, W, Cy, dtype=torch.bfloat16, device="cuda")
-    ops.conv_igemm(d, dz, wp, out0)
-    red0 = torch.zeros(ops.STAT_REPLICAS, 2, Cy, device="cuda")
-    ops.bn_bwd_reduce(zprev, Cy, out0, Cy, None, 0, None, Cy, scale, shift, mean, invstd, red0, N, H, W, Cy, relu=1)
-    out1 = torch.empty_like(out0)
-    red1 = torch.zeros_like(red0)
-    ops.conv_igemm_bnred(d, dz, wp, out1, zprev, Cy, scale, shift, mean, invstd, red1)
-    torch.cuda.synchronize()
-    assert torch.equal(out1, out0)
-    a, b = red1.sum(0).cpu(), red0.sum(0).cpu()
-    assert float((a - b).abs().max()) < 2e-4 * float(b.abs().max()) + 1e-3, (a - b).abs().max()
-    # not the 3x3 halo path -> refused, not silently unfused
-    d2 = ops.conv_desc(N, H, W, Cz, Cz, H, W, Cy, Cy, 1, 1, 1, 0, 1, cpad)
-    assert not ops.conv_is_halo3x3(d2)
-    with pytest.raises(Exception):
-        ops.conv_igemm_bnred(d2, dz, wp, out1, zprev, Cy, scale, shift, mean, invstd, red1)
-
-
 def test_convT_forward_shuffle_and_dgrad(ops):
     N, H, W, Ci, Co = 2, 8, 12, 64, 32
     g = torch.Generator().manual_seed(23)
