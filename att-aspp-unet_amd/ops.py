@@ -44,6 +44,16 @@ def stats_buffer(C: int, device="cuda") -> torch.Tensor:
     return torch.zeros(stat_words(C), dtype=torch.int64, device=device)
 
 
+def _check_stats(stats, C: int, what: str):
+    """The kernels add into [R][2][C] two-limb int64 slots + a poison word: a buffer sized for anything else (e.g. the
+    fp32 [R][2][C] of round 1) would be written out of bounds, so the size is checked on the host."""
+    if stats is None:
+        return
+    if stats.dtype != torch.int64 or stats.numel() < stat_words(C) or not stats.is_contiguous():
+        raise _abi.AauError(f"{what}: stats must be a contiguous int64 tensor of >= {stat_words(C)} words for {C} channels "
+                            f"(ops.stats_buffer), got {stats.dtype} x {stats.numel()}")
+
+
 def stats_totals(stats: torch.Tensor, C: int) -> torch.Tensor:
     """fp64 [2, C]: (sum, sum of squares) per channel of an aau_stat buffer."""
     out = torch.empty(2, C, dtype=torch.float64, device=stats.device)
@@ -52,6 +62,7 @@ def stats_totals(stats: torch.Tensor, C: int) -> torch.Tensor:
 
 
 def fold_stats(stats, C, which, c_begin, n, out):
+    _check_stats(stats, C, "fold_stats")
     check(fn("aau_fold_stats")(_p(stats), C, which, c_begin, n, _p(out), _stream()), "aau_fold_stats")
 
 
@@ -80,6 +91,7 @@ def conv_desc(N, H, W, Cin, src_pitch, Ho, Wo, Cout, dst_pitch, KH=1, KW=1, stri
 
 
 def conv_igemm(desc: ConvDesc, src, wpk, dst, bias=None, scale=None, shift=None, stats=None):
+    _check_stats(stats, desc.Cout, "conv_igemm")
     check(fn("aau_conv_igemm")(C.byref(desc), _p(src), _p(wpk), _p(dst), _p(bias), _p(scale), _p(shift),
                                _p(stats), _stream()), "aau_conv_igemm")
 
@@ -122,6 +134,7 @@ def conv_wgrad_group(descs, srcs, dzs, dws):
 
 
 def conv1_fwd(x, w, z, stats, N, H, W, Cc):
+    _check_stats(stats, Cc, "conv1_fwd")
     check(fn("aau_conv1_fwd")(_p(x), _p(w), _p(z), _p(stats), N, H, W, Cc, _stream()), "aau_conv1_fwd")
 
 
@@ -136,6 +149,7 @@ def pack_weights(flat, packed, table_dev, n_entries, total_blocks):
 
 def bn_finalize(stats, gamma, beta, rmean, rvar, nbt, scale, shift, smean, sinvstd, Cc, count,
                 eps=1e-5, momentum=0.1):
+    _check_stats(stats, Cc, "bn_finalize")
     check(fn("aau_bn_finalize")(_p(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(scale),
                                 _p(shift), _p(smean), _p(sinvstd), Cc, count, eps, momentum, _stream()),
           "aau_bn_finalize")
@@ -228,6 +242,7 @@ def spatial_sum(src, sp, out, ws, N, HW, Cc):
 
 
 def gate_psi(zg, zx, sg, hg, sx, hx, wpsi, psi_pre, stats, M, Fi):
+    _check_stats(stats, 1, "gate_psi")
     check(fn("aau_gate_psi")(_p(zg), _p(zx), _p(sg), _p(hg), _p(sx), _p(hx), _p(wpsi), _p(psi_pre),
                              _p(stats), M, Fi, _stream()), "aau_gate_psi")
 

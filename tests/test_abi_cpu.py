@@ -37,3 +37,18 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     assert b"Cin" in lib.aau_last_error()
     with pytest.raises(_abi.AauError):
         _abi.check(rc, "aau_conv_igemm")
+
+
+def test_statistics_buffers_are_size_checked_on_the_host():
+    """A statistics buffer of the wrong type / size (e.g. the fp32 [R][2][C] of round 1) is refused before any kernel
+    could add past its end (ops._check_stats): the wrappers raise without touching the GPU."""
+    import torch
+    from att_aspp_unet_amd import ops, _abi
+    d = ops.conv_desc(1, 16, 16, 32, 32, 16, 16, 64, 64, 3, 3, 1, 1, 1, 32)
+    dummy = torch.zeros(8)
+    for bad in (torch.zeros(ops.STAT_REPLICAS, 2, 64), torch.zeros(ops.stat_words(64) - 1, dtype=torch.int64)):
+        with pytest.raises(_abi.AauError, match="stats must be"):
+            ops.conv_igemm(d, dummy, dummy, dummy, stats=bad)
+        with pytest.raises(_abi.AauError, match="stats must be"):
+            ops.bn_finalize(bad, *([dummy] * 9), 64, 256.0)
+    assert ops.stats_buffer(64, device="cpu").numel() == ops.stat_words(64)
