@@ -45,14 +45,37 @@ __device__ __forceinline__ void ldf8(const float* p, float f[8]) {
 }
 
 // ------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const long long* stats, const float* gamma, const float* beta,
-                                   float* rmean, float* rvar, int64_t* nbt, float* scale, float* shift,
-                                   float* smean, float* sinvstd, int C, float count, float eps, float mom) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    // exact integer fold of the fixed-point replicas (common.h); mean / variance formed in fp64, rounded once
-    const double s1 = stat_total(stats, C, 0, c), s2 = stat_total(stats, C, 1, c);
+// 256 threads = 8 channels x 32 replica lanes: a lane loads its replica's two (hi, lo) pairs with 16-B loads, the 32
+// lanes are added with shuffles (integers: exact, any order), lane 0 forms mean / variance in fp64 and rounds once.
+// (One thread per channel walking the 32 replicas took 10-15 us per launch, 31 launches per step.)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const long long* stats, const float* gamma, const float* beta,
+                                                          float* rmean, float* rvar, int64_t* nbt, float* scale,
+                                                          float* shift, float* smean, float* sinvstd, int C, float count,
+                                                          float eps, float mom) {
+    static_assert(AAU_STAT_REPLICAS == 32, "one replica per lane of a 32-lane group");
+    typedef __attribute__((ext_vector_type(2))) long long i64x2;
+    const int r = threadIdx.x & 31;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    const bool ok = c < C;
+    i64x2 a = i64x2{0, 0}, b = i64x2{0, 0};
+    if (ok) {
+        a = *(const i64x2*)(stats + (((size_t)r * 2 + 0) * C + c) * 2);
+        b = *(const i64x2*)(stats + (((size_t)r * 2 + 1) * C + c) * 2);
+    }
+    long long h1 = a[0], l1 = a[1], h2 = b[0], l2 = b[1];
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+        h1 += __shfl_xor(h1, o, 32);
+        l1 += __shfl_xor(l1, o, 32);
+        h2 += __shfl_xor(h2, o, 32);
+        l2 += __shfl_xor(l2, o, 32);
+    }
+    if (!ok || r != 0) return;
+    const bool poisoned = stats[(size_t)AAU_STAT_REPLICAS * 2 * C * 2] != 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double s1 = poisoned ? nan : (double)h1 * (1.0 / 256.0) + (double)l1 * (1.0 / 4503599627370496.0);
+    const double s2 = poisoned ? nan : (double)h2 * (1.0 / 256.0) + (double)l2 * (1.0 / 4503599627370496.0);
     const double mean_d = s1 / (double)count;
     const float mean = (float)mean_d;
     const float var = fmaxf((float)(s2 / (double)count - mean_d * mean_d), 0.f);
@@ -537,7 +560,7 @@ extern "C" int aau_bn_finalize(const aau_stat* stats, const float* gamma, const 
     AAU_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd, "aau_bn_finalize: null pointer");
     AAU_REQUIRE(C > 0 && count > 0, "aau_bn_finalize: C=%d count=%lld", C, (long long)count);
     ProfScope prof(2, 0, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, gamma,
                        beta, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C,
                        (float)count, eps, momentum);
     return check_launch("aau_bn_finalize");
