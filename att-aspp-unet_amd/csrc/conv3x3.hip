@@ -577,6 +577,12 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
 // Every wave issues the same number of LDS-DMA instructions (the spare ones are all-out-of-range pieces that land in
 // a 1-KB scratch area), so the loop has no divergent code and the vmcnt counts are constants.
 // LDS: two halo buffers (42 KB) + 2 slots of 3 tap tiles (36 KB) + scratch = 79 KB -> two workgroups per CU.
+// Where the time goes (scripts/bench_c3fixed.py + the AAU_C3_ABL / AAU_C3_NOSTORE timing ablations, 8 x 256 x 256,
+// 384 -> 96 channels): the bare read + MFMA + barrier loop runs at 1741 TFLOP/s; the weight LDS-DMA costs 9 %, the
+// halo LDS-DMA 12 %, the output stores 5 %, the statistics epilogue 3-5 %: 1300 as shipped.  ~5 us per workgroup
+// (address tables, first round trip, epilogue) do not shrink with Cin; a PERSISTENT form that carried the chunk
+// stream across tile boundaries (next tile's first halo / weights in flight under the epilogue, statistics published
+// once) measured +-0 on every layer at 256 VGPRs + spills and was removed again.
 template <int BQ>
 __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
     static_assert(BQ % 32 == 0, "two channel halves of whole 16-channel tiles");
@@ -707,9 +713,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
         {
             int t2 = tx + 1, c2 = chunk;
             if (t2 == 3) { t2 = 0; ++c2; }
-            issue_w(slot ^ 1, c2, t2);
+            if (!(a.rev & 4)) issue_w(slot ^ 1, c2, t2);      // (rev & 4 / 8: timing-only ablations, AAU_C3_ABL)
         }
-        if (tx == 0) issue_halo(chunk + 1, buf ^ 1);
+        if (tx == 0 && !(a.rev & 8)) issue_halo(chunk + 1, buf ^ 1);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -801,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
             u32x2 pk;
             pk[0] = pack2(v[0], v[1]);
             pk[1] = pack2(v[2], v[3]);
-            *(u32x2*)out = pk;
+            if (!(a.rev & 2)) *(u32x2*)out = pk;   // (rev & 2: timing-only ablation, AAU_C3_NOSTORE)
         }
     }
     if (want_stats) {
@@ -1830,8 +1836,10 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
             hipFuncSetAttribute((const void*)conv3x3h_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attrh = true;
         }
-        prof_tag("conv3x3h<96>");
         const size_t ldsh = (size_t)(2 * 336 * 32 + 2 * 3 * 96 * 32 + 512) * 2;
+        prof_tag("conv3x3h<96>");
+        if (getenv("AAU_C3_NOSTORE")) a.rev |= 2;
+        if (const char* e = getenv("AAU_C3_ABL")) a.rev |= atoi(e) & 12;
         hipLaunchKernelGGL((conv3x3h_kernel<96>), dim3((unsigned)grid), dim3(256), ldsh, s, a);
         return check_launch("aau_conv_igemm(3x3 halo, column steps)");
     }
