@@ -16,3 +16,4 @@ from . import ablation, evalseg, gc_wrapper, imgproc  # noqa: F401
 from .imgproc import refine_mask  # noqa: F401
 from .pipeline import calibrate, predict, predict_masks, predict_prob_tta_batch  # noqa: F401
 from .parallel import DataParallel, GradBucketReducer, bucket_ranges  # noqa: F401
+from ._abi import AauError, precision  # noqa: F401

@@ -121,7 +121,9 @@ _SIGS = {
     "aau_window_blend": [P, P, I, I, I, I, I, I, F, P],
 }
 
-_lib = None
+_libs: dict = {}
+_kind = "bf16"          # which build of the library calls resolve to: "bf16" (libaau.so) or "fp16" (libaau_f16.so)
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": LIB_PATH.replace("libaau.so", "libaau_f16.so")}
 
 
 def declared_symbols() -> list[str]:
@@ -131,14 +133,16 @@ def declared_symbols() -> list[str]:
     return sorted(set(re.findall(r"\b(aau_[a-z0-9_]+)\s*\(", text)))
 
 
-def lib() -> C.CDLL:
-    """Load the library (once).  Fails loudly when it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise AauError(f"{LIB_PATH} not found: run `python __graft_entry__.py` / build() first "
+def lib(kind: str | None = None) -> C.CDLL:
+    """Load the library of the current 16-bit storage type (once).  Fails loudly when it has not been built."""
+    kind = kind or _kind
+    l = _libs.get(kind)
+    if l is None:
+        path = LIB_PATHS[kind]
+        if not os.path.exists(path):
+            raise AauError(f"{path} not found: run `python __graft_entry__.py` / build() first "
                            "(there is no non-HIP fallback)")
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         l.aau_last_error.restype = C.c_char_p
         l.aau_last_error.argtypes = []
         l.aau_version.restype = C.c_int
@@ -149,8 +153,32 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int
         l.aau_bn_red_ws_bytes.restype = C.c_int64
         l.aau_bn_red_ws_bytes.argtypes = [C.c_int]
-        _lib = l
-    return _lib
+        _libs[kind] = l
+    return l
+
+
+class precision:
+    """``with precision("fp16"):`` -- calls made (and launch lists recorded) inside resolve to the IEEE-half build of the
+    library (inference only: the reference's fp16 configuration); the default is the bfloat16 build."""
+
+    def __init__(self, kind: str):
+        if kind not in LIB_PATHS:
+            raise AauError(f"unknown precision {kind!r} (bf16 | fp16)")
+        self.kind = kind
+
+    def __enter__(self):
+        global _kind
+        self.prev, _kind = _kind, self.kind
+        return self
+
+    def __exit__(self, *exc):
+        global _kind
+        _kind = self.prev
+        return False
+
+
+def current_precision() -> str:
+    return _kind
 
 
 def check(rc: int, what: str = "") -> None:

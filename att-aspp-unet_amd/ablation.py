@@ -81,6 +81,11 @@ class AttentionASPPUNet(nn.Module):
     def engine(self) -> Engine:
         return self._engine
 
+    def set_precision(self, kind: str):
+        """"bf16" (default) or "fp16" (IEEE half, inference only); see model.AttentionASPPUNet.set_precision."""
+        self._engine.set_precision(kind)
+        return self
+
     def _plan_for(self, x):
         if x.dim() != 4 or x.shape[1] != 1:
             raise _abi.AauError(f"expected input [B,1,H,W], got {tuple(x.shape)}")

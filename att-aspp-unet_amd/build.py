@@ -67,7 +67,15 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") 
     return lib_out
 
 
+def build_all(force: bool = False, verbose: bool = True) -> list:
+    """Both storage types: libaau.so (bfloat16) and libaau_f16.so (IEEE half, inference)."""
+    return [build(force, verbose), build(force, verbose, defines=("AAU_F16",), tag="f16")]
+
+
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     tags = [a[6:] for a in sys.argv[1:] if a.startswith("--tag=")]
-    print(build(force="--force" in sys.argv, defines=defs, tag=tags[0] if tags else ""))
+    if not defs and not tags:
+        print(build_all(force="--force" in sys.argv))
+    else:
+        print(build(force="--force" in sys.argv, defines=defs, tag=tags[0] if tags else ""))

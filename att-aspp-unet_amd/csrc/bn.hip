@@ -446,10 +446,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
             yy = row % H;
         };
         auto fma_px = [&](const u32x2& zq, const u32x2& gq, const f32x2 v[5]) {
-            const float zz[4] = {__uint_as_float(zq[0] << 16), __uint_as_float(zq[0] & 0xffff0000u),
-                                 __uint_as_float(zq[1] << 16), __uint_as_float(zq[1] & 0xffff0000u)};
-            const float g[4] = {__uint_as_float(gq[0] << 16), __uint_as_float(gq[0] & 0xffff0000u),
-                                __uint_as_float(gq[1] << 16), __uint_as_float(gq[1] & 0xffff0000u)};
+            const float zz[4] = {pair_lo(zq[0]), pair_hi(zq[0]),
+                                 pair_lo(zq[1]), pair_hi(zq[1])};
+            const float g[4] = {pair_lo(gq[0]), pair_hi(gq[0]),
+                                pair_lo(gq[1]), pair_hi(gq[1])};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float gm = (zz[j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;

@@ -5,8 +5,19 @@
 #include <stdio.h>
 #include "aau.h"
 
+// 16-bit storage type of activations and packed weights.  The library is built twice from the same sources:
+// libaau.so (bfloat16: training and inference, the metric's dtype) and libaau_f16.so (-DAAU_F16: IEEE half, for the
+// reference's fp16 inference configuration -- no loss scaling exists here, so training stays bf16).  Kernels only
+// touch the type through these names: `bf16x8` (an MFMA operand), AAU_MFMA16, bf2f / f2bf / pair_lo / pair_hi.
+#ifdef AAU_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4;
+#define AAU_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define AAU_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -44,20 +55,33 @@ static inline void zero_f32(float* p, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
 }
 
-// ---- bf16 <-> f32 (round to nearest even; plain casts keep NaN a NaN, see guide) ----
+// ---- 16-bit storage <-> f32 (round to nearest even; plain casts keep NaN a NaN, see guide) ----
+#ifdef AAU_F16
+__device__ __forceinline__ float bf2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    _Float16 b = (_Float16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+// the two values of a packed pair
+__device__ __forceinline__ float pair_lo(unsigned u) { return bf2f((unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float pair_hi(unsigned u) { return bf2f((unsigned short)(u >> 16)); }
+#else
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
 }
+__device__ __forceinline__ float pair_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float pair_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
 __device__ __forceinline__ void unpack8(const u32x4& v, float f[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        f[2 * i] = __uint_as_float(v[i] << 16);
-        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+        f[2 * i] = pair_lo(v[i]);
+        f[2 * i + 1] = pair_hi(v[i]);
     }
 }
 __device__ __forceinline__ u32x4 pack8(const float f[8]) {

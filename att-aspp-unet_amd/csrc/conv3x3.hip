@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], cur[mi], acc[ni][mi], 0, 0, 0);
+                acc[ni][mi] = AAU_MFMA16(wf[ni], cur[mi], acc[ni][mi], 0, 0, 0);
     };
 
     // ---- software pipeline over S = nchunk*9 (chunk, tap) steps ----
@@ -287,10 +287,10 @@ __global__ __launch_bounds__(256 * PW) void conv3x3_kernel(const C3Args a) {
             unsigned short* out = a.dst + pixel * d.dst_pitch + q;
             if (d.accumulate) {
                 const u32x2 old = *(const u32x2*)out;
-                v[0] += __uint_as_float(old[0] << 16);
-                v[1] += __uint_as_float(old[0] & 0xffff0000u);
-                v[2] += __uint_as_float(old[1] << 16);
-                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                v[0] += pair_lo(old[0]);
+                v[1] += pair_hi(old[0]);
+                v[2] += pair_lo(old[1]);
+                v[3] += pair_hi(old[1]);
             }
             if (d.relu) {
 #pragma unroll
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -522,10 +522,10 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
             unsigned short* out = a.dst + pixel * d.dst_pitch + q;
             if (d.accumulate) {
                 const u32x2 old = *(const u32x2*)out;
-                v[0] += __uint_as_float(old[0] << 16);
-                v[1] += __uint_as_float(old[0] & 0xffff0000u);
-                v[2] += __uint_as_float(old[1] << 16);
-                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                v[0] += pair_lo(old[0]);
+                v[1] += pair_hi(old[0]);
+                v[2] += pair_lo(old[1]);
+                v[3] += pair_hi(old[1]);
             }
             if (d.relu) {
 #pragma unroll
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k][ni], af[mi + k], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = AAU_MFMA16(wf[k][ni], af[mi + k], acc[ni][mi], 0, 0, 0);
         // schedule: 4 reads, then one read per MFMA until the 10 + 3*NI fragments are in, then one LDS-DMA per 4 MFMAs
         constexpr int NRD = MI + 2 + 3 * NI, NMF = 3 * NI * MI;
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -795,10 +795,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
             unsigned short* out = a.dst + pixel * d.dst_pitch + q;
             if (d.accumulate) {
                 const u32x2 old = *(const u32x2*)out;
-                v[0] += __uint_as_float(old[0] << 16);
-                v[1] += __uint_as_float(old[0] & 0xffff0000u);
-                v[2] += __uint_as_float(old[1] << 16);
-                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                v[0] += pair_lo(old[0]);
+                v[1] += pair_hi(old[0]);
+                v[2] += pair_lo(old[1]);
+                v[3] += pair_hi(old[1]);
             }
             if (d.relu) {
 #pragma unroll
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(320) void conv3x3l_kernel(const C3Args a) {
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -1035,10 +1035,10 @@ __global__ __launch_bounds__(320) void conv3x3l_kernel(const C3Args a) {
             unsigned short* out = a.dst + pixel * d.dst_pitch + q;
             if (d.accumulate) {
                 const u32x2 old = *(const u32x2*)out;
-                v[0] += __uint_as_float(old[0] << 16);
-                v[1] += __uint_as_float(old[0] & 0xffff0000u);
-                v[2] += __uint_as_float(old[1] << 16);
-                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                v[0] += pair_lo(old[0]);
+                v[1] += pair_hi(old[0]);
+                v[2] += pair_lo(old[1]);
+                v[3] += pair_hi(old[1]);
             }
             if (d.relu) {
 #pragma unroll
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
 #ifdef AAU_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
 #ifdef AAU_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
 #ifdef AAU_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1649,10 +1649,10 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
                 }
                 if (d.accumulate) {
                     const u32x2 old = *(const u32x2*)out;
-                    v[0] += __uint_as_float(old[0] << 16);
-                    v[1] += __uint_as_float(old[0] & 0xffff0000u);
-                    v[2] += __uint_as_float(old[1] << 16);
-                    v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                    v[0] += pair_lo(old[0]);
+                    v[1] += pair_hi(old[0]);
+                    v[2] += pair_lo(old[1]);
+                    v[3] += pair_hi(old[1]);
                 }
                 if (d.relu) {
 #pragma unroll

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
 #ifdef AAU_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             }
             if (d.accumulate) {
                 const u32x2 old = *(const u32x2*)out;
-                v[0] += __uint_as_float(old[0] << 16);
-                v[1] += __uint_as_float(old[0] & 0xffff0000u);
-                v[2] += __uint_as_float(old[1] << 16);
-                v[3] += __uint_as_float(old[1] & 0xffff0000u);
+                v[0] += pair_lo(old[0]);
+                v[1] += pair_hi(old[0]);
+                v[2] += pair_lo(old[1]);
+                v[3] += pair_hi(old[1]);
             }
             if (d.relu) {
 #pragma unroll

@@ -200,17 +200,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             const bf16x8 af0 = AAU_FRAG8(alo[0], ahi[0]), af1 = AAU_FRAG8(alo[1], ahi[1]), af2 = AAU_FRAG8(alo[2], ahi[2]);
             {
                 const bf16x8 bf = AAU_FRAG8(blo[0], bhi[0]);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf, acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf, acc[1][0], 0, 0, 0);
-                acc[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2, bf, acc[2][0], 0, 0, 0);
+                acc[0][0] = AAU_MFMA16(af0, bf, acc[0][0], 0, 0, 0);
+                acc[1][0] = AAU_MFMA16(af1, bf, acc[1][0], 0, 0, 0);
+                acc[2][0] = AAU_MFMA16(af2, bf, acc[2][0], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]));
 #pragma unroll
             for (int j = 1; j < 3; ++j) {
                 const bf16x8 bf = AAU_FRAG8(blo[j], bhi[j]);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf, acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf, acc[1][j], 0, 0, 0);
-                acc[2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2, bf, acc[2][j], 0, 0, 0);
+                acc[0][j] = AAU_MFMA16(af0, bf, acc[0][j], 0, 0, 0);
+                acc[1][j] = AAU_MFMA16(af1, bf, acc[1][j], 0, 0, 0);
+                acc[2][j] = AAU_MFMA16(af2, bf, acc[2][j], 0, 0, 0);
             }
         }
     };

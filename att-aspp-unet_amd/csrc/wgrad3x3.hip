@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
             for (int n = 0; n < 3; ++n) {
                 const bf16x8 bf = AAU_FRAG8(blo[n], bhi[n]);
 #pragma unroll
-                for (int i = 0; i < QW; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+                for (int i = 0; i < QW; ++i) acc[i][n] = AAU_MFMA16(af[i], bf, acc[i][n], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[3]), "+v"(blo[4]), "+v"(blo[5]), "+v"(blo[6]), "+v"(bhi[3]),
                          "+v"(bhi[4]), "+v"(bhi[5]), "+v"(bhi[6]));
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
                 if (n < nct) {   // wave-uniform
                     const bf16x8 bf = AAU_FRAG8(blo[n], bhi[n]);
 #pragma unroll
-                    for (int i = 0; i < QW; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+                    for (int i = 0; i < QW; ++i) acc[i][n] = AAU_MFMA16(af[i], bf, acc[i][n], 0, 0, 0);
                 }
             }
         }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
                 for (int u = 0; u < 3; ++u) {
                     const bf16x8 bf = AAU_FRAG8(B[t][2 * ss + u], B[t][2 * ss + u + 1]);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) acc[i][t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][t][u], 0, 0, 0);
+                    for (int i = 0; i < 3; ++i) acc[i][t][u] = AAU_MFMA16(af[i], bf, acc[i][t][u], 0, 0, 0);
                 }
         }
     };

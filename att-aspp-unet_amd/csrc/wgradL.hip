@@ -205,14 +205,14 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
         for (int j = 0; j < 3; ++j) {
             const bf16x8 bf = WL_FRAG(blo[j], bhi[j]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 6; ++i) acc[i][j] = AAU_MFMA16(af[i], bf, acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[3]), "+v"(blo[4]), "+v"(blo[5]), "+v"(bhi[3]), "+v"(bhi[4]), "+v"(bhi[5]));
 #pragma unroll
         for (int j = 3; j < 6; ++j) {
             const bf16x8 bf = WL_FRAG(blo[j], bhi[j]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 6; ++i) acc[i][j] = AAU_MFMA16(af[i], bf, acc[i][j], 0, 0, 0);
         }
     };
 

@@ -59,6 +59,7 @@ class _Rec:
     def __init__(self):
         self.ops = []
         self.keep = []
+        self.kind = _abi.current_precision()    # the library build (bf16 / fp16) these launches were recorded against
         self.side = None        # torch.cuda.Stream, created on first use
         self.uses_side = False
         self.wg_ops = []        # (op index, workspace bytes) of the weight-gradient launches
@@ -108,7 +109,7 @@ class _Rec:
     def run(self, stream: int):
         # alternate the traversal direction of the streaming kernels (aau_traverse): a consumer that starts where
         # its producer finished finds that end of a > 128 MB tensor still in the 256-MiB Infinity Cache
-        trav = _abi.fn("aau_traverse")
+        trav = _abi.lib(self.kind).aau_traverse
         trav(0 if _NO_TRAVERSE else 1)
         try:
             self._run(stream)
@@ -130,7 +131,7 @@ class _Rec:
 
     def run_ops(self, ops_, stream: int, first: bool, last: bool):
         """One segment of ``segments()``.  The traversal parity (aau_traverse) runs on across the segments."""
-        trav = _abi.fn("aau_traverse")
+        trav = _abi.lib(self.kind).aau_traverse
         if first:
             trav(0 if _NO_TRAVERSE else 1)
         try:
@@ -148,7 +149,7 @@ class _Rec:
             side = side_t.cuda_stream
             main_t = torch.cuda.current_stream()
         prof = _abi.PROF_ON
-        setlab = _abi.fn("aau_prof_label") if prof else None
+        setlab = _abi.lib(self.kind).aau_prof_label if prof else None
         for f, a, name, sid, lab in (self.ops if ops_ is None else ops_):
             if f is None:
                 if name == "fork":
@@ -299,6 +300,8 @@ class ParamStore:
                 b.dgamma, b.dbeta = self.gviews[mname + ".weight"], self.gviews[mname + ".bias"]
                 b.rm, b.rv, b.nbt = m.running_mean, m.running_var, m.num_batches_tracked
                 self.bns[mname] = b
+        # 16-bit operand images written by aau_pack_weights at the head of every forward list: bf16 or (fp16 plans) IEEE
+        # half bit patterns -- the torch dtype of this buffer is only a label
         self.packed = torch.zeros(max(dst, 8), dtype=BF16, device=self.device)
         for cp in self.convs.values():
             for key in ("pk_f", "pk_d"):
@@ -355,7 +358,8 @@ class Plan:
         self.bwd.bind_wgrad_ws(self.dev)
 
     # ---- small helpers ----
-    def new(self, *shape, dtype=BF16):
+    def new(self, *shape, dtype=None):
+        dtype = self.eng.adt if dtype is None else dtype
         return torch.zeros(*shape, dtype=dtype, device=self.dev)
 
     def bnbuf(self, C_):
@@ -815,6 +819,7 @@ class Engine:
         self.model = model
         self.store: ParamStore | None = None
         self.plans: dict = {}
+        self.precision = "bf16"  # 16-bit storage type of the launch lists: "bf16", or "fp16" (inference only)
         self._seed = None       # dropout seed chain: drawn from torch's RNG (and the DP rank) on first use
         self.bucket_cb = None   # set by the data-parallel wrapper: name -> callable
         import os
@@ -858,8 +863,22 @@ class Engine:
             return None
         return lambda n=name: self.bucket_cb(n)
 
+    def set_precision(self, kind: str):
+        """"bf16" (default; training and inference) or "fp16" (IEEE half, the reference's fp16 inference configuration
+        ``pipeline:320,437``: forward only -- there is no loss scaling here, training stays bf16)."""
+        if kind not in _abi.LIB_PATHS:
+            raise _abi.AauError(f"unknown precision {kind!r} (bf16 | fp16)")
+        if kind != self.precision:
+            _abi.lib(kind)          # fail loudly if that build of the library is missing
+            self.precision = kind   # plans are keyed by it: launch lists are recorded against one build of the library
+
+    @property
+    def adt(self):
+        """torch dtype of the 16-bit activation tensors of this engine's plans."""
+        return torch.float16 if self.precision == "fp16" else BF16
+
     def ensure(self, device):
-        _abi.lib()  # fail loudly if the HIP library is missing
+        _abi.lib(self.precision)  # fail loudly if the HIP library is missing
         if device.type != "cuda":
             raise _abi.AauError("the MI355X path needs CUDA/HIP tensors; there is no CPU fallback "
                                 "(the CPU restatement lives in oracle/ and is test infrastructure only)")
@@ -877,9 +896,13 @@ class Engine:
 
     def plan(self, B, H, W, train) -> Plan:
         key = (B, H, W, bool(train), self.dropout_p() if train else 0.0,
-               self.bucket_cb is not None, self.overlap_wgrad)
+               self.bucket_cb is not None, self.overlap_wgrad, self.precision)
         p = self.plans.get(key)
         if p is None:
-            p = Plan(self, B, H, W, bool(train))
+            if train and self.precision != "bf16":
+                raise _abi.AauError("fp16 is an inference precision here (no loss scaling): call model.eval() or "
+                                    "set_precision('bf16') to train")
+            with _abi.precision(self.precision):
+                p = Plan(self, B, H, W, bool(train))
             self.plans[key] = p
         return p

@@ -40,14 +40,14 @@ def preprocess_sweep(u8: torch.Tensor) -> torch.Tensor:
 
 
 class FetalAbdomenSegmentation:
-    def __init__(self, checkpoint_path=None, base=16, device="cuda"):
+    def __init__(self, checkpoint_path=None, base=16, device="cuda", precision="fp16"):
         self.device = torch.device(device)
         self.net = AttentionASPPUNet(in_channels=1, num_classes=1, base_c=base).to(self.device)
         if checkpoint_path is not None:
             sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
             miss, unexp = self.net.load_state_dict(sd, strict=False)
             print(f"[DEBUG] load_state — missing:{len(miss)} unexpected:{len(unexp)}")
-        self.net.eval()
+        self.net.eval().set_precision(precision)     # the reference wrapper runs fp32; half is the closest 16-bit type
         self.case_id = None
 
     @torch.no_grad()

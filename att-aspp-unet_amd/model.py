@@ -171,6 +171,12 @@ class AttentionASPPUNet(nn.Module):
     def engine(self) -> Engine:
         return self._engine
 
+    def set_precision(self, kind: str):
+        """16-bit storage type of the activations: "bf16" (default) or "fp16" -- IEEE half for inference, what the
+        reference's ``torch.cuda.amp.autocast`` gives its GPU predict path (pipeline:320,437).  Returns self."""
+        self._engine.set_precision(kind)
+        return self
+
     def _plan_for(self, x):
         if x.dim() != 4 or x.shape[1] != 1:
             raise _abi.AauError(f"expected input [B,1,H,W], got {tuple(x.shape)}")

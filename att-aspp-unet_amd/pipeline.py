@@ -127,7 +127,7 @@ def calibrate(args):
     device = torch.device("cuda")
     model = AttentionASPPUNet(base_c=args.base_c).to(device)
     model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
-    model.eval()
+    model.eval().set_precision(getattr(args, "precision", "fp16"))
     val_dir = Path(args.val_dir)
     imgs = sorted((val_dir / "images").glob("*.png"))
     thrs = np.linspace(0.1, 0.9, 17)
@@ -165,7 +165,9 @@ def predict(args):
             pass
     model = AttentionASPPUNet(base_c=args.base_c).to(device)
     model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
-    model.eval()
+    # the reference predicts in fp32 (pipeline:436-437); IEEE half is 8x closer to that than bfloat16 at the same speed
+    # (tests/test_fp16_gpu.py), so inference entry points default to it; training stays bf16
+    model.eval().set_precision(getattr(args, "precision", "fp16"))
     od = Path(args.out_dir)
     od.mkdir(exist_ok=True, parents=True)
     done = []
@@ -457,7 +459,9 @@ def get_args(argv=None):
     pr.add_argument("--weights", required=True); pr.add_argument("--input_dir", required=True)
     pr.add_argument("--out_dir", default="./preds"); pr.add_argument("--spacing_json", required=True)
     pr.add_argument("--base_c", type=int, default=48)
+    pr.add_argument("--precision", choices=["fp16", "bf16"], default="fp16")
     ca = sp.add_parser("calibrate")
     ca.add_argument("--weights", required=True); ca.add_argument("--val_dir", required=True)
     ca.add_argument("--output_dir", default="./checkpoints"); ca.add_argument("--base_c", type=int, default=48)
+    ca.add_argument("--precision", choices=["fp16", "bf16"], default="fp16")
     return p.parse_args(argv)

@@ -177,8 +177,14 @@ def inference_numbers(dev):
     big = torch.rand(1, 1, 1024, 1024, device=dev)
     gf9 = A.GraphedForward(m5, (9, 1, 512, 512), device=dev)
     t5 = timeit(lambda: A.predict_sliding_window(m5, big, 512, 256, forward=gf9), n=10)
+    # the same window batch in IEEE half (libaau_f16.so), the dtype BASELINE.json states for config 5
+    m5.set_precision("fp16")
+    gf9h = A.GraphedForward(m5, (9, 1, 512, 512), device=dev)
+    t5h = timeit(lambda: A.predict_sliding_window(m5, big, 512, 256, forward=gf9h), n=10)
     return {"config2_fwd_bs4_512_bf16_hipgraph": {"ms": t2 * 1e3, "images_per_sec": 4 / t2,
                                                   "conv_tflops": 4 * 226.76e9 / t2 / 1e12},
+            "config5_1024_sliding_window_9x512_rates_6_12_18_24_fp16_hipgraph": {"ms_per_frame": t5h * 1e3,
+                                                                                 "frames_per_sec": 1 / t5h},
             "config5_1024_sliding_window_9x512_rates_6_12_18_24_bf16_hipgraph": {"ms_per_frame": t5 * 1e3,
                                                                                  "frames_per_sec": 1 / t5}}
 
