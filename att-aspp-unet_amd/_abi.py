@@ -75,9 +75,9 @@ _SIGS = {
     "aau_spatial_sum": [P, I, P, P, I, I, I, P],
     "aau_gate_psi": [P, P, P, P, P, P, P, P, P, L, I, P],
     "aau_gate_apply": [P, I, P, P, P, P, P, I, L, I, P],
-    "aau_gate_bwd1": [P, I, P, I, P, P, P, P, P, I, P, P, L, I, P],
-    "aau_gate_bwd2": [P] * 23 + [L, I, P],
-    "aau_gate_bwd3": [P] * 19 + [L, I, P],
+    "aau_gate_bwd1": [P, I, P, I, P, P, P, P, P, I, P, P, L, I, P, P],
+    "aau_gate_bwd2": [P] * 21 + [L, I, P, P],
+    "aau_gate_bwd3": [P] * 17 + [L, I, P],
     "aau_gate2_fwd": [P, P, P, P, P, I, P, P, I, L, I, I, P],
     "aau_gate2_bwd": [P, I, P, I, P, P, P, P, P, I, P, P, P, P, L, I, I, P],
     "aau_fold_stats": [P, I, I, I, I, P, P],

@@ -103,7 +103,7 @@ def aspp_forward(mod, x):
     for i, blk in enumerate(mod.blocks):
         conv_bn(blk[0], blk[1], xh, out=cat[:, i * Cb:], out_pitch=ncat, training=mod.training)
     pooled = torch.empty(B, 1, 1, in_c, dtype=BF16, device=x.device)
-    ops.gap_fwd(xh, in_c, pooled, torch.empty(B, in_c, device=x.device), B, H * W, in_c)
+    ops.gap_fwd(xh, in_c, pooled, torch.empty(ops.GAP_WS_ROWS, B, in_c, device=x.device), B, H * W, in_c)
     conv_bn(mod.pool[1], mod.pool[2], pooled, out=cat[:, nbr * Cb:], out_pitch=ncat, training=mod.training,
             bcast_hw=H * W)
     y, _, _, _ = conv_bn(mod.project[0], mod.project[1], cat.view(B, H, W, ncat), training=mod.training)

@@ -367,7 +367,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
 // Last step of the backward pass: BatchNorm+ReLU backward of d1[0] fused with the weight gradient of its
 // Conv2d(1, C, 3, pad 1) (pipeline:113).  The first layer has no input gradient, so dz is consumed here and never
 // written (-2 tensor passes of the largest activation).  dz is rounded to bf16 exactly as the stored form would be.
-// ws: [AAU_STAT_REPLICAS][C*9] fp32 partial sums (zeroed by the caller, folded into dw afterwards).
+// ws: one row [C*9] of weight-gradient partial sums per workgroup (threads combined in a fixed order through LDS);
+// red_fold_launch adds the rows in row order into dw: no float atomics.
 __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned short* z, int zp, const float* gamma,
                                                                  const float* mean, const float* invstd,
                                                                  const float* red, float* dgamma, float* dbeta, int M,
@@ -375,9 +376,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
                                                                  const float* scale, const float* shift,
                                                                  const float* x, int H, int W, float* ws,
                                                                  const float* wconv, int ppb) {
-    extern __shared__ float sm[];   // [2][C] replica sums, [C*9] workgroup accumulators, [C*9] conv weights (z == null)
-    float* sacc = sm + 2 * C;
-    float* swc = sm + 11 * C;
+    extern __shared__ float sm[];   // [2][C] BN sums, [C*9] conv weights (z == null), [pixel lanes][C*9] thread partials
+    float* swc = sm + 2 * C;
+    float* spart = sm + 11 * C;
     if (!z)
         for (int i = threadIdx.x; i < C * 9; i += 256) swc[i] = wconv[i];
     for (int cc = threadIdx.x; cc < C; cc += 256) {
@@ -389,7 +390,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
             if (dgamma) dgamma[cc] += b;
         }
     }
-    for (int i = threadIdx.x; i < C * 9; i += 256) sacc[i] = 0.f;
     __syncthreads();
     // A thread owns FOUR channels (not the eight of the other BN kernels): 36 accumulators + 20 constants keep
     // it under 96 VGPRs, i.e. 5 waves per SIMD -- at 8 channels (184 VGPRs, 2 waves) the loop was latency bound
@@ -477,19 +477,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) atomicAdd(&sacc[(c + j) * 9 + k], acc[j][k >> 1][k & 1]);
+            for (int k = 0; k < 9; ++k) spart[(size_t)pl * C * 9 + (c + j) * 9 + k] = acc[j][k >> 1][k & 1];
     }
     __syncthreads();
-    float* rep = ws + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * C * 9;
-    for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(rep + i, sacc[i]);
-}
-
-__global__ void fold_conv1_kernel(const float* ws, float* dw, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float a = 0.f;
-    for (int r = 0; r < AAU_STAT_REPLICAS; ++r) a += ws[(size_t)r * n + i];
-    dw[i] += a;
+    float* row = red_row(ws, C * 9, blockIdx.x);
+    for (int i = threadIdx.x; i < C * 9; i += 256) {
+        float a = 0.f;
+        for (int q = 0; q < PL4; ++q) a += spart[(size_t)q * C * 9 + i];     // pixel lanes in lane order
+        row[i] = a;
+    }
 }
 
 // rows per block so that the grid is ~8 workgroups per CU and every thread gets a few iterations
@@ -623,7 +619,7 @@ extern "C" int aau_maxpool2(const aau_bf16* y, int y_pitch, aau_bf16* p, int p_p
 
 extern "C" int64_t aau_bn_red_ws_bytes(int C) {
     if (C <= 0) return 0;
-    return (int64_t)red_ws_floats(3 * C + 8, AAU_BN_RED_MAX_BLOCKS) * (int64_t)sizeof(float);
+    return (int64_t)red_ws_floats(9 * C + 8, AAU_BN_RED_MAX_BLOCKS) * (int64_t)sizeof(float);   // widest row: C*9 (first layer dw)
 }
 
 extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16* dy, int dy_pitch,
@@ -724,10 +720,10 @@ extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const floa
     AAU_REQUIRE(C <= 1024, "aau_bn_bwd_apply_conv1: C=%d too wide for one workgroup", C);
     rows_split(M, 256 / (C >> 2), &blocks, &ppb);
     const int ppb_signed = next_traversal() ? -(int)ppb : (int)ppb;
-    zero_f32(ws, (int64_t)AAU_STAT_REPLICAS * C * 9, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel, dim3((unsigned)blocks), dim3(256), (2 * C + 9 * C + 9 * C) * sizeof(float),
+    const int PL4 = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
+    hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(2 * C + 9 * C + PL4 * 9 * C) * sizeof(float),
                        (hipStream_t)stream, z, z_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, (int)M, C, dy,
                        dy_pitch, scale, shift, x, H, W, ws, w, ppb_signed);
-    hipLaunchKernelGGL(fold_conv1_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9);
+    red_fold_launch(ws, C * 9, (int)blocks, nullptr, 0, dw, C * 9, nullptr, (hipStream_t)stream);
     return check_launch("aau_bn_bwd_apply_conv1");
 }

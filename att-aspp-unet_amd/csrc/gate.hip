@@ -117,11 +117,11 @@ __global__ __launch_bounds__(256) void gate_apply_kernel(const unsigned short* x
     }
 }
 
-// channel-group threads: dx = dout*alpha ; dq = <dout, x> * alpha(1-alpha) ; red1 += (dq, dq*psihat)
+// channel-group threads: dx = dout*alpha ; dq = <dout, x> * alpha(1-alpha) ; rows of (sum dq, sum dq*psihat) -> red1
 __global__ __launch_bounds__(256) void gate_bwd1_kernel(const unsigned short* dout, int dop, const unsigned short* x,
                                                         int xp, const float* alpha, const float* psi_pre,
                                                         const float* mean1, const float* invstd1,
-                                                        unsigned short* dx, int dxp, float* dq, float* red1,
+                                                        unsigned short* dx, int dxp, float* dq, float* ws,
                                                         int64_t M, int C, int64_t ppb) {
     __shared__ float part[256];
     __shared__ float s4[4];
@@ -158,11 +158,7 @@ __global__ __launch_bounds__(256) void gate_bwd1_kernel(const unsigned short* do
     }
     const float a = block_sum1(t1, s4);
     const float b = block_sum1(t2, s4);
-    if (tid == 0) {
-        float* r = red1 + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * 2;
-        atomicAdd(r, a);
-        atomicAdd(r + 1, b);
-    }
+    if (tid == 0) *(f32x4*)red_row(ws, 4, blockIdx.x) = f32x4{a, b, 0.f, 0.f};   // this workgroup's row; red_fold adds the rows in order
 }
 
 // channel-group threads: ds, dwpsi, per-channel sums for the two branch BNs
@@ -170,14 +166,13 @@ __global__ __launch_bounds__(256) void gate_bwd2_kernel(
     const float* dq, const float* psi_pre, const float* red1, const float* gamma1, const float* mean1,
     const float* invstd1, const unsigned short* zg, const unsigned short* zx, const float* sg, const float* hg,
     const float* sx, const float* hx, const float* mean_g, const float* invstd_g, const float* mean_x,
-    const float* invstd_x, const float* wpsi, unsigned short* ds, float* dwpsi_rep, float* redg, float* redx,
+    const float* invstd_x, const float* wpsi, unsigned short* ds, float* ws,
     float* dgamma1, float* dbeta1, int64_t M, int F, int64_t ppb) {
     __shared__ float sred[256 * 8];
     const CGMap3 mp(F);
     const int tid = threadIdx.x;
     const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
-    float r1 = 0.f, r2 = 0.f;
-    for (int r = 0; r < AAU_STAT_REPLICAS; ++r) { r1 += red1[2 * r]; r2 += red1[2 * r + 1]; }
+    const float r1 = red1[0], r2 = red1[1];      // totals of step 1
     if (blockIdx.x == 0 && tid == 0) {
         if (dbeta1) dbeta1[0] += r1;
         if (dgamma1) dgamma1[0] += r2;
@@ -223,46 +218,33 @@ __global__ __launch_bounds__(256) void gate_bwd2_kernel(
         }
         if (m < m1) body(m, psi_pre[m], dq[m], *(const u32x4*)(zg + m * F + c), *(const u32x4*)(zx + m * F + c));
     }
-    const int rep = blockIdx.x % AAU_STAT_REPLICAS;
+    // this workgroup's row [dpsi*s | d | d*zhat_g | d*zhat_x][F]; red_fold adds the rows in a fixed order into `tot`
+    float* row = red_row(ws, 4 * F, blockIdx.x);
+    auto put = [&](const float a[8], int k) {
+        *(f32x4*)(row + k * F + c) = f32x4{a[0], a[1], a[2], a[3]};
+        *(f32x4*)(row + k * F + c + 4) = f32x4{a[4], a[5], a[6], a[7]};
+    };
     block_sum8c(a_w, sred, mp, tid);
-    if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(dwpsi_rep + (size_t)rep * F + c + j, a_w[j]);   // replicas: one shared row serialises the adds
-    }
+    if (tid < mp.CG) put(a_w, 0);
     block_sum8c(a_s, sred, mp, tid);
-    if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            atomicAdd(redg + (size_t)rep * 2 * F + c + j, a_s[j]);
-            atomicAdd(redx + (size_t)rep * 2 * F + c + j, a_s[j]);
-        }
-    }
+    if (tid < mp.CG) put(a_s, 1);
     block_sum8c(a_g, sred, mp, tid);
-    if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(redg + (size_t)rep * 2 * F + F + c + j, a_g[j]);
-    }
+    if (tid < mp.CG) put(a_g, 2);
     block_sum8c(a_x, sred, mp, tid);
-    if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(redx + (size_t)rep * 2 * F + F + c + j, a_x[j]);
-    }
+    if (tid < mp.CG) put(a_x, 3);
 }
 
 __global__ __launch_bounds__(256) void gate_bwd3_kernel(
     const unsigned short* ds, const unsigned short* zg, const unsigned short* zx, const float* gamma_g,
-    const float* mean_g, const float* invstd_g, const float* redg, const float* gamma_x, const float* mean_x,
-    const float* invstd_x, const float* redx, unsigned short* dzg, unsigned short* dzx, float* dgamma_g,
-    float* dbeta_g, float* dgamma_x, float* dbeta_x, const float* dwpsi_rep, float* dwpsi, int64_t M, int F) {
+    const float* mean_g, const float* invstd_g, const float* gamma_x, const float* mean_x,
+    const float* invstd_x, const float* tot, unsigned short* dzg, unsigned short* dzx, float* dgamma_g,
+    float* dbeta_g, float* dgamma_x, float* dbeta_x, float* dwpsi, int64_t M, int F) {
     extern __shared__ float sm[];  // [6][F]
     float* g0 = sm; float* g1 = sm + F; float* g2 = sm + 2 * F;
     float* x0 = sm + 3 * F; float* x1 = sm + 4 * F; float* x2 = sm + 5 * F;
     for (int c = threadIdx.x; c < F; c += 256) {
-        float a = 0.f, b = 0.f, a2 = 0.f, b2 = 0.f;
-        for (int r = 0; r < AAU_STAT_REPLICAS; ++r) {
-            a += redg[(size_t)r * 2 * F + c]; b += redg[(size_t)r * 2 * F + F + c];
-            a2 += redx[(size_t)r * 2 * F + c]; b2 += redx[(size_t)r * 2 * F + F + c];
-        }
+        // tot [4][F] = (sum dpsi*s, sum d, sum d*zhat_g, sum d*zhat_x) of step 2
+        const float a = tot[F + c], b = tot[2 * F + c], a2 = a, b2 = tot[3 * F + c];
         g0[c] = gamma_g[c] * invstd_g[c]; g1[c] = a / (float)M; g2[c] = b / (float)M;
         x0[c] = gamma_x[c] * invstd_x[c]; x1[c] = a2 / (float)M; x2[c] = b2 / (float)M;
         if (blockIdx.x == 0) {
@@ -270,11 +252,7 @@ __global__ __launch_bounds__(256) void gate_bwd3_kernel(
             if (dgamma_g) dgamma_g[c] += b;
             if (dbeta_x) dbeta_x[c] += a2;
             if (dgamma_x) dgamma_x[c] += b2;
-            if (dwpsi) {
-                float w = 0.f;
-                for (int r = 0; r < AAU_STAT_REPLICAS; ++r) w += dwpsi_rep[(size_t)r * F + c];
-                dwpsi[c] += w;
-            }
+            if (dwpsi) dwpsi[c] += tot[c];
         }
     }
     __syncthreads();
@@ -343,21 +321,24 @@ extern "C" int aau_gate_apply(const aau_bf16* x, int x_pitch, const float* psi_p
 
 extern "C" int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x_pitch,
                              const float* alpha, const float* psi_pre, const float* mean1, const float* invstd1,
-                             aau_bf16* dx, int dx_pitch, float* dq, float* red1, int64_t M, int C, void* stream) {
-    AAU_REQUIRE(dout && x && alpha && psi_pre && mean1 && invstd1 && dx && dq && red1 && M > 0,
+                             aau_bf16* dx, int dx_pitch, float* dq, float* red1, int64_t M, int C, float* ws,
+                             void* stream) {
+    AAU_REQUIRE(dout && x && alpha && psi_pre && mean1 && invstd1 && dx && dq && red1 && ws && M > 0,
                 "aau_gate_bwd1: bad args");
+    AAU_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)red1 & 15) == 0, "aau_gate_bwd1: red1 / ws must be 16-byte aligned");
     CHK_F("aau_gate_bwd1", C);
     AAU_REQUIRE(dout_pitch % 8 == 0 && x_pitch % 8 == 0 && dx_pitch % 8 == 0, "aau_gate_bwd1: pitch");
     ProfScope prof(2, 0, (hipStream_t)stream);
     const CGMap3 mp(C);
     int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
-    if (b > 4096) b = 4096;
+    if (b > AAU_BN_RED_MAX_BLOCKS) b = AAU_BN_RED_MAX_BLOCKS;
     if (b < 1) b = 1;
     int64_t ppb = ((M + b - 1) / b + mp.PL - 1) / mp.PL * mp.PL;
     b = (M + ppb - 1) / ppb;
     if (next_traversal()) ppb = -ppb;
     hipLaunchKernelGGL(gate_bwd1_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dout, dout_pitch, x,
-                       x_pitch, alpha, psi_pre, mean1, invstd1, dx, dx_pitch, dq, red1, M, C, ppb);
+                       x_pitch, alpha, psi_pre, mean1, invstd1, dx, dx_pitch, dq, ws, M, C, ppb);
+    red_fold_launch(ws, 4, (int)b, red1, 4, nullptr, 0, nullptr, (hipStream_t)stream);
     return check_launch("aau_gate_bwd1");
 }
 
@@ -365,18 +346,19 @@ extern "C" int aau_gate_bwd2(const float* dq, const float* psi_pre, const float*
                              const float* mean1, const float* invstd1, const aau_bf16* zg, const aau_bf16* zx,
                              const float* sg, const float* hg, const float* sx, const float* hx,
                              const float* mean_g, const float* invstd_g, const float* mean_x,
-                             const float* invstd_x, const float* wpsi, aau_bf16* ds, float* dwpsi_rep, float* redg,
-                             float* redx, float* dgamma1, float* dbeta1, int64_t M, int F, void* stream) {
+                             const float* invstd_x, const float* wpsi, aau_bf16* ds, float* tot, float* dgamma1,
+                             float* dbeta1, int64_t M, int F, float* ws, void* stream) {
     AAU_REQUIRE(dq && psi_pre && red1 && gamma1 && mean1 && invstd1 && zg && zx && sg && hg && sx && hx && mean_g &&
-                    invstd_g && mean_x && invstd_x && wpsi && ds && dwpsi_rep && redg && redx && M > 0,
+                    invstd_g && mean_x && invstd_x && wpsi && ds && tot && ws && M > 0,
                 "aau_gate_bwd2: bad args");
+    AAU_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)tot & 15) == 0, "aau_gate_bwd2: tot / ws must be 16-byte aligned");
     CHK_F("aau_gate_bwd2", F);
     const CGMap3 mp(F);
     // 16 pixels per thread (two in flight): every workgroup ends with 4 block reductions + replica atomics, so
     // fewer, longer workgroups win (8: +20-40 %, 4: +60-100 %)
     int64_t b = (M + (int64_t)mp.PL * 16 - 1) / ((int64_t)mp.PL * 16);
     if (const char* e = getenv("AAU_GB2_PPT")) b = (M + (int64_t)mp.PL * atoi(e) - 1) / ((int64_t)mp.PL * atoi(e));   // experiment
-    if (b > 4096) b = 4096;
+    if (b > AAU_BN_RED_MAX_BLOCKS) b = AAU_BN_RED_MAX_BLOCKS;
     if (b < 1) b = 1;
     int64_t ppb = (M + b - 1) / b;
     b = (M + ppb - 1) / ppb;
@@ -384,22 +366,23 @@ extern "C" int aau_gate_bwd2(const float* dq, const float* psi_pre, const float*
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(gate_bwd2_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, dq, psi_pre, red1,
                        gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x, invstd_x, wpsi, ds,
-                       dwpsi_rep, redg, redx, dgamma1, dbeta1, M, F, ppb);
+                       ws, dgamma1, dbeta1, M, F, ppb);
+    red_fold_launch(ws, 4 * F, (int)b, tot, 4 * F, nullptr, 0, nullptr, (hipStream_t)stream);
     return check_launch("aau_gate_bwd2");
 }
 
 extern "C" int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_bf16* zx, const float* gamma_g,
-                             const float* mean_g, const float* invstd_g, const float* redg, const float* gamma_x,
-                             const float* mean_x, const float* invstd_x, const float* redx, aau_bf16* dzg,
+                             const float* mean_g, const float* invstd_g, const float* gamma_x,
+                             const float* mean_x, const float* invstd_x, const float* tot, aau_bf16* dzg,
                              aau_bf16* dzx, float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x,
-                             const float* dwpsi_rep, float* dwpsi, int64_t M, int F, void* stream) {
-    AAU_REQUIRE(ds && zg && zx && gamma_g && mean_g && invstd_g && redg && gamma_x && mean_x && invstd_x && redx &&
-                    dzg && dzx && M > 0 && (!dwpsi || dwpsi_rep), "aau_gate_bwd3: bad args");
+                             float* dwpsi, int64_t M, int F, void* stream) {
+    AAU_REQUIRE(ds && zg && zx && gamma_g && mean_g && invstd_g && gamma_x && mean_x && invstd_x && tot &&
+                    dzg && dzx && M > 0, "aau_gate_bwd3: bad args");
     CHK_F("aau_gate_bwd3", F);
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(gate_bwd3_kernel, dim3(grid1(M * (F / 8))), dim3(256), 6 * F * sizeof(float),
-                       (hipStream_t)stream, ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x,
-                       redx, dzg, dzx, dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi_rep, dwpsi, M, F);
+                       (hipStream_t)stream, ds, zg, zx, gamma_g, mean_g, invstd_g, gamma_x, mean_x, invstd_x,
+                       tot, dzg, dzx, dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi, M, F);
     return check_launch("aau_gate_bwd3");
 }
 

@@ -16,7 +16,15 @@ namespace aau {
 // sums layout per sample: 0 sum t, 1 sum p, 2 sum p*t, 3 sum bce, 4 sum |gp-gt|, 5 sum pbin, 6 sum pbin*t
 constexpr int NS = 8;
 constexpr int TILE = 16;
-constexpr int NREP = AAU_STAT_REPLICAS;  // sums workspace = [NREP][B][NS]: same-address atomics are spread over replicas
+constexpr int NREP = AAU_STAT_REPLICAS;  // sums workspace = fp32 [NREP][B][NS] (the ABI's size)
+// Inside that workspace: the first [B][NS] floats are the per-sample table the consumers read; behind it live
+// NACC replicas of int64 [B][NS] fixed-point accumulators (value * 2^32; tile sums stay below 2^30) and a poison word.
+// Integer adds are associative: the per-sample sums -- loss, Dice, the gradient of the criterion -- do not depend on the
+// order in which the 8192 tiles arrive (the fp32-atomic form did).  A non-finite tile sum raises the poison word and the
+// table becomes NaN, which keeps the reference's skip-the-step-on-inf/nan behaviour (pipeline:322-324).
+constexpr int NACC = 14;
+static_assert((NACC * 2 + 1) * NS + 2 <= NREP * NS, "accumulators must fit behind the table");
+__device__ __forceinline__ unsigned long long* crit_acc(float* sums, int B) { return (unsigned long long*)(sums + (size_t)B * NS); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 // numerically stable BCE-with-logits element: max(x,0) - x*t + log1p(exp(-|x|))
@@ -74,18 +82,27 @@ __global__ __launch_bounds__(256) void crit_reduce_kernel(const float* logits, c
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         const float s = block_sum(v[k], s4);
-        if (tid == 0 && s != 0.f)
-            atomicAdd(sums + ((size_t)((blockIdx.x + blockIdx.y) % NREP) * gridDim.z + b) * NS + k, s);
+        if (tid == 0 && s != 0.f) {
+            unsigned long long* acc = crit_acc(sums, (int)gridDim.z);
+            if (!(fabsf(s) < 1.0e9f)) {
+                atomicOr(acc + (size_t)NACC * gridDim.z * NS, 1ull);                  // poison
+            } else {
+                const long long q = (long long)rint((double)s * 4294967296.0);
+                atomicAdd(acc + ((size_t)((blockIdx.x + blockIdx.y) % NACC) * gridDim.z + b) * NS + k, (unsigned long long)q);
+            }
+        }
     }
 }
 
-// collapse the replicas into replica 0 so that the consumers read one [B][NS] table
+// fold the fixed-point replicas into the fp32 table [B][NS] at the head of the workspace
 __global__ void crit_fold_kernel(float* sums, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * NS) return;
-    float a = 0.f;
-    for (int r = 0; r < NREP; ++r) a += sums[(size_t)r * B * NS + i];
-    sums[i] = a;
+    const unsigned long long* acc = crit_acc(sums, B);
+    long long a = 0;
+    for (int r = 0; r < NACC; ++r) a += (long long)acc[(size_t)r * B * NS + i];
+    const bool poisoned = acc[(size_t)NACC * B * NS] != 0;
+    sums[i] = poisoned ? __uint_as_float(0x7fc00000u) : (float)((double)a * (1.0 / 4294967296.0));
 }
 
 struct CritTerms {  // per-launch scalars derived from the per-sample sums

@@ -9,6 +9,8 @@
 
 namespace aau {
 
+// One partial per workgroup into out[1 + blockIdx.x]; sqnorm_fold_kernel adds the partials in index order into out[0]
+// (no float atomics: the clip coefficient, and with it the whole update, is bitwise reproducible).
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, int64_t n, float inv_scale, float* out) {
     __shared__ float s4[4];
     float acc = 0.f;
@@ -24,7 +26,20 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, int64_t n, 
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, s4[0] + s4[1] + s4[2] + s4[3]);
+    if (threadIdx.x == 0) out[1 + blockIdx.x] = s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+__global__ __launch_bounds__(256) void sqnorm_fold_kernel(float* out, int nblk) {
+    __shared__ float s[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) a += out[1 + i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 256; ++i) t += s[i];
+        out[0] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, float* m, float* v, const float* g, int64_t n,
@@ -140,11 +155,11 @@ extern "C" int aau_grad_sqnorm(const float* grad, int64_t n, float inv_scale, fl
     AAU_REQUIRE(((uintptr_t)grad & 15) == 0, "aau_grad_sqnorm: grad must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(3, 0, s);
-    zero_f32(norm_ws, 1, s);
     int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > AAU_SQNORM_WS - 4) blocks = AAU_SQNORM_WS - 4;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grad, n, inv_scale, norm_ws);
+    hipLaunchKernelGGL(sqnorm_fold_kernel, dim3(1), dim3(256), 0, s, norm_ws, (int)blocks);
     return check_launch("aau_grad_sqnorm");
 }
 

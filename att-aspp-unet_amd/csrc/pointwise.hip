@@ -446,15 +446,20 @@ __global__ __launch_bounds__(256) void spatial_sum_kernel(const unsigned short* 
         }
     }
     block_sum8b(s, sred, mp, tid);
-    if (tid < mp.CG) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(acc32 + (int64_t)n * C + c + j, s[j]);
+    if (tid < mp.CG) {   // this pixel slab's row of image n: rows [slab][n][C], added in slab order by the next kernel
+        float* r = acc32 + ((int64_t)blockIdx.x * gridDim.y + n) * C + c;
+        *(f32x4*)r = f32x4{s[0], s[1], s[2], s[3]};
+        *(f32x4*)(r + 4) = f32x4{s[4], s[5], s[6], s[7]};
     }
 }
 
-__global__ void scale_to_bf16_kernel(const float* src, unsigned short* dst, int64_t n, float alpha) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        dst[i] = f2bf(src[i] * alpha);
+// dst[i] = alpha * sum over the nrow slab rows (fixed order) of src[row][i]
+__global__ void scale_to_bf16_kernel(const float* src, unsigned short* dst, int64_t n, float alpha, int nrow) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float a = 0.f;
+        for (int r = 0; r < nrow; ++r) a += src[(int64_t)r * n + i];
+        dst[i] = f2bf(a * alpha);
+    }
 }
 
 // dx[n][p][c] += dpooled[n][c] * inv_hw
@@ -656,12 +661,11 @@ extern "C" int aau_outconv_bwd(const aau_bf16* y, int y_pitch, const float* dlog
 static int spatial_reduce(const aau_bf16* src, int sp, aau_bf16* out, int N, int HW, int C, float alpha,
                           float* ws, hipStream_t s) {
     const int64_t need = (int64_t)N * C;
-    zero_f32(ws, need, s);
     const CGMap2 mp(C);
     int64_t blocks, ppb;
-    split_rows(HW, mp.PL, 8, 64, &blocks, &ppb);
+    split_rows(HW, mp.PL, 8, AAU_GAP_WS_ROWS, &blocks, &ppb);
     hipLaunchKernelGGL(spatial_sum_kernel, dim3((unsigned)blocks, N), dim3(256), 0, s, src, sp, ws, HW, C, ppb);
-    hipLaunchKernelGGL(scale_to_bf16_kernel, dim3(grid1d(need)), dim3(256), 0, s, ws, out, need, alpha);
+    hipLaunchKernelGGL(scale_to_bf16_kernel, dim3(grid1d(need)), dim3(256), 0, s, ws, out, need, alpha, (int)blocks);
     return check_launch("spatial reduce");
 }
 

@@ -219,7 +219,7 @@ class ParamStore:
         self._ptrs = [p.data_ptr() for p in self.params]
         self.m = self.v = None  # Adam moments, allocated by the optimiser
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=device)
-        self.norm_ws = torch.zeros(4, dtype=F32, device=device)
+        self.norm_ws = torch.zeros(ops.SQNORM_WS, dtype=F32, device=device)   # [0] = |g|^2, rest: workgroup partials
         self._build_pack(model)
 
     @staticmethod
@@ -444,7 +444,7 @@ class Plan:
             if fuse1:
                 # first layer: no input gradient, so the apply pass feeds the weight gradient directly
                 b.add("aau_bn_bwd_apply_conv1", r["z"], cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
-                      bn.dbeta, N, H, W, cv.O, dy, dyp, w["scale"], w["shift"], r["src"], cv.w, cv.dw, self.rep_ws)
+                      bn.dbeta, N, H, W, cv.O, dy, dyp, w["scale"], w["shift"], r["src"], cv.w, cv.dw, self.red_ws)
                 return None
             b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
                   bn.dbeta, M, cv.O, dy, dyp, w["scale"], w["shift"], 1, dp_, self.drop_seed)
@@ -546,7 +546,7 @@ class Plan:
             br = [self.cbr_fwd(f"bridge.blocks.{i}.0", f"bridge.blocks.{i}.1", p4, Cs[3], B, h5, w5,
                                cat5[:, i * Cb:], ncat) for i in range(nbr)]
             pooled = self.new(B, Cs[3])
-            gap_ws = self.new(B, max(Cs[3], Cb), dtype=F32)
+            gap_ws = self.new(ops.GAP_WS_ROWS, B, max(Cs[3], Cb), dtype=F32)     # one row per pixel slab
             f.label = "bridge.pool"
             f.add("aau_gap_fwd", p4, Cs[3], pooled, gap_ws, B, h5 * w5, Cs[3])
             rpool = self.cbr_fwd("bridge.pool.1", "bridge.pool.2", pooled, Cs[3], B, 1, 1, cat5[:, nbr * Cb:], ncat,
@@ -675,16 +675,17 @@ class Plan:
                 w1, wgb, wxb = gt["w1"], gt["wgb"], gt["wxb"]
                 dq = self.new(Mo, dtype=F32)
                 ds, dzg, dzx = self.new(Mo, Fi), self.new(Mo, Fi), self.new(Mo, Fi)
-                red1 = w1["red"]
+                red1 = w1["red"]                         # fp32 [4]: totals of step 1
+                tot = self.red_arena.take(4 * Fi)        # fp32 [4][Fi]: totals of step 2
                 b.add("aau_gate_bwd1", dcat, 2 * Co, skips[lv], skip_p[lv], gt["alpha"], gt["psi_pre"], w1["mean"],
-                      w1["invstd"], dskip[lv], Co, dq, red1, Mo, Co)
+                      w1["invstd"], dskip[lv], Co, dq, red1, Mo, Co, self.red_ws)
                 b.add("aau_gate_bwd2", dq, gt["psi_pre"], red1, gt["b1"].gamma, w1["mean"], w1["invstd"], gt["zg"],
                       gt["zx"], wgb["scale"], wgb["shift"], wxb["scale"], wxb["shift"], wgb["mean"], wgb["invstd"],
-                      wxb["mean"], wxb["invstd"], gt["psi"].w, ds, gt["wrep"], wgb["red"], wxb["red"],
-                      gt["b1"].dgamma, gt["b1"].dbeta, Mo, Fi)
-                b.add("aau_gate_bwd3", ds, gt["zg"], gt["zx"], gt["bg"].gamma, wgb["mean"], wgb["invstd"], wgb["red"],
-                      gt["bx"].gamma, wxb["mean"], wxb["invstd"], wxb["red"], dzg, dzx, gt["bg"].dgamma,
-                      gt["bg"].dbeta, gt["bx"].dgamma, gt["bx"].dbeta, gt["wrep"], gt["psi"].dw, Mo, Fi)
+                      wxb["mean"], wxb["invstd"], gt["psi"].w, ds, tot, gt["b1"].dgamma, gt["b1"].dbeta, Mo, Fi,
+                      self.red_ws)
+                b.add("aau_gate_bwd3", ds, gt["zg"], gt["zx"], gt["bg"].gamma, wgb["mean"], wgb["invstd"],
+                      gt["bx"].gamma, wxb["mean"], wxb["invstd"], tot, dzg, dzx, gt["bg"].dgamma,
+                      gt["bg"].dbeta, gt["bx"].dgamma, gt["bx"].dbeta, gt["psi"].dw, Mo, Fi)
                 wg, wx = gt["wg"], gt["wx"]
                 ov = eng.overlap_wgrad
                 if ov:

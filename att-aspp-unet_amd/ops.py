@@ -213,7 +213,9 @@ def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, C
 
 def bn_bwd_apply_conv1(z, zp, gamma, smean, sinvstd, red, dgamma, dbeta, N, H, W, Cc, dy, dyp, scale, shift, x, dw, ws,
                        w=None):
-    """z None: recomputed from x and the conv weights ``w`` [C][9]."""
+    """z None: recomputed from x and the conv weights ``w`` [C][9].  ws: None or >= bn_red_ws_bytes(Cc)."""
+    if ws is None or ws.numel() * ws.element_size() < bn_red_ws_bytes(Cc):
+        ws = bn_red_ws(Cc, dw.device)
     check(fn("aau_bn_bwd_apply_conv1")(_p(z), zp, _p(gamma), _p(smean), _p(sinvstd), _p(red), _p(dgamma), _p(dbeta),
                                        N, H, W, Cc, _p(dy), dyp, _p(scale), _p(shift), _p(x), _p(w), _p(dw), _p(ws),
                                        _stream()), "aau_bn_bwd_apply_conv1")
@@ -229,7 +231,13 @@ def conv1_bn_bwd_reduce(x, w, dy, dyp, scale, shift, smean, sinvstd, red, N, H, 
                                         N, H, W, Cc, _p(ws), _stream()), "aau_conv1_bn_bwd_reduce")
 
 
+def _check_gap_ws(ws, N, Cc, what):
+    if ws.dtype != torch.float32 or ws.numel() < GAP_WS_ROWS * N * Cc:
+        raise _abi.AauError(f"{what}: workspace must be fp32 [{GAP_WS_ROWS}][N][C] = {GAP_WS_ROWS * N * Cc} floats, got {ws.numel()}")
+
+
 def gap_fwd(x, xp, pooled, ws, N, HW, Cc):
+    _check_gap_ws(ws, N, Cc, "gap_fwd")
     check(fn("aau_gap_fwd")(_p(x), xp, _p(pooled), _p(ws), N, HW, Cc, _stream()), "aau_gap_fwd")
 
 
@@ -238,6 +246,7 @@ def gap_bwd(dpooled, dx, dxp, N, HW, Cc):
 
 
 def spatial_sum(src, sp, out, ws, N, HW, Cc):
+    _check_gap_ws(ws, N, Cc, "spatial_sum")
     check(fn("aau_spatial_sum")(_p(src), sp, _p(out), _p(ws), N, HW, Cc, _stream()), "aau_spatial_sum")
 
 
@@ -252,23 +261,26 @@ def gate_apply(x, xp, psi_pre, scale1, shift1, alpha, out, op, M, Cc):
                                _stream()), "aau_gate_apply")
 
 
-def gate_bwd1(dout, dop, x, xp, alpha, psi_pre, mean1, invstd1, dx, dxp, dq, red1, M, Cc):
+def gate_bwd1(dout, dop, x, xp, alpha, psi_pre, mean1, invstd1, dx, dxp, dq, red1, M, Cc, ws=None):
+    """red1: fp32 [4], overwritten with (sum dq, sum dq*psihat, 0, 0)."""
+    ws = bn_red_ws(Cc, red1.device) if ws is None else ws
     check(fn("aau_gate_bwd1")(_p(dout), dop, _p(x), xp, _p(alpha), _p(psi_pre), _p(mean1), _p(invstd1),
-                              _p(dx), dxp, _p(dq), _p(red1), M, Cc, _stream()), "aau_gate_bwd1")
+                              _p(dx), dxp, _p(dq), _p(red1), M, Cc, _p(ws), _stream()), "aau_gate_bwd1")
 
 
 def gate_bwd2(dq, psi_pre, red1, gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x,
-              invstd_x, wpsi, ds, dwpsi_rep, redg, redx, dgamma1, dbeta1, M, Fi):
-    """dwpsi_rep: zeroed fp32 [STAT_REPLICAS][Fi]; gate_bwd3 folds it into the psi weight gradient."""
+              invstd_x, wpsi, ds, tot, dgamma1, dbeta1, M, Fi, ws=None):
+    """tot: fp32 [4][Fi], overwritten with (psi weight gradient, sum ds, sum ds*zhat_g, sum ds*zhat_x)."""
+    ws = bn_red_ws(2 * Fi, tot.device) if ws is None else ws
     args = [dq, psi_pre, red1, gamma1, mean1, invstd1, zg, zx, sg, hg, sx, hx, mean_g, invstd_g, mean_x,
-            invstd_x, wpsi, ds, dwpsi_rep, redg, redx, dgamma1, dbeta1]
-    check(fn("aau_gate_bwd2")(*[_p(a) for a in args], M, Fi, _stream()), "aau_gate_bwd2")
+            invstd_x, wpsi, ds, tot, dgamma1, dbeta1]
+    check(fn("aau_gate_bwd2")(*[_p(a) for a in args], M, Fi, _p(ws), _stream()), "aau_gate_bwd2")
 
 
-def gate_bwd3(ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x, redx, dzg, dzx,
-              dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi_rep, dwpsi, M, Fi):
-    args = [ds, zg, zx, gamma_g, mean_g, invstd_g, redg, gamma_x, mean_x, invstd_x, redx, dzg, dzx,
-            dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi_rep, dwpsi]
+def gate_bwd3(ds, zg, zx, gamma_g, mean_g, invstd_g, gamma_x, mean_x, invstd_x, tot, dzg, dzx,
+              dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi, M, Fi):
+    args = [ds, zg, zx, gamma_g, mean_g, invstd_g, gamma_x, mean_x, invstd_x, tot, dzg, dzx,
+            dgamma_g, dbeta_g, dgamma_x, dbeta_x, dwpsi]
     check(fn("aau_gate_bwd3")(*[_p(a) for a in args], M, Fi, _stream()), "aau_gate_bwd3")
 
 
@@ -342,7 +354,13 @@ def seg_counts(a, b):
     return int(na), int(nb), int(ni)
 
 
+SQNORM_WS = 1028   # aau.h: AAU_SQNORM_WS
+GAP_WS_ROWS = 64   # aau.h: AAU_GAP_WS_ROWS
+
+
 def grad_sqnorm(grad, n, inv_scale, ws):
+    if ws.dtype != torch.float32 or ws.numel() < SQNORM_WS:
+        raise _abi.AauError(f"grad_sqnorm: workspace must be fp32 [{SQNORM_WS}] (ws[0] = result), got {ws.dtype} x {ws.numel()}")
     check(fn("aau_grad_sqnorm")(_p(grad), n, inv_scale, _p(ws), _stream()), "aau_grad_sqnorm")
 
 

@@ -220,7 +220,8 @@ int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
 
 /* First layer (pipeline:113 d1[0]): the apply pass fused with the weight gradient of its   */
 /* Conv2d(1, C, 3, pad 1) -- the layer has no input gradient, so dz is never written.     */
-/* x: the fp32 frame [N][H][W]; dw: [C][9] fp32 (+=); ws: fp32 [32][C*9] scratch.          */
+/* x: the fp32 frame [N][H][W]; dw: [C][9] fp32 (+=); ws: aau_bn_red_ws_bytes(C) (rows of   */
+/* partial sums, added in a fixed order).                                                   */
 /* z == NULL: z is recomputed from x and the conv weights w [C][9] (see aau_conv1_bn_act). */
 int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const float* gamma, const float* save_mean,
                            const float* save_invstd, const float* red, float* dgamma, float* dbeta,
@@ -239,7 +240,9 @@ int aau_conv1_bn_bwd_reduce(const float* x, const float* w, const aau_bf16* dy, 
                             float* ws, void* stream);
 
 /* ---- ASPP image-pool branch (pipeline:75-77,82) -------------------------------------- */
-/* ws: caller-provided fp32 [N*C] workspace (zeroed by the call)                        */
+/* ws: caller-provided fp32 [AAU_GAP_WS_ROWS][N][C] workspace: one row of sums per pixel   */
+/* slab, added in slab order (no float atomics)                                          */
+#define AAU_GAP_WS_ROWS 64
 int aau_gap_fwd(const aau_bf16* x, int x_pitch, aau_bf16* pooled, float* ws, int N, int HW, int C, void* stream);
 /* dsrc[n][p][c] += dpooled[n][c] / HW  (accumulate into bf16)                           */
 int aau_gap_bwd(const aau_bf16* dpooled, aau_bf16* dx, int dx_pitch, int N, int HW, int C, void* stream);
@@ -256,32 +259,33 @@ int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float* sg, const 
 int aau_gate_apply(const aau_bf16* x, int x_pitch, const float* psi_pre, const float* scale1,
                    const float* shift1, float* alpha, aau_bf16* out, int out_pitch, int64_t M,
                    int C, void* stream);
+/* The per-channel sums of the three backward steps are added in a fixed order (workgroup  */
+/* rows in `ws` = aau_bn_red_ws_bytes(C) + one fold launch): no float atomics.              */
 /* backward step 1: dx[m,c] = dout*alpha; dq[m] = (sum_c dout*x) * alpha*(1-alpha);          */
-/* red1 [REPLICAS][2][1] += (dq, dq*psihat)                                                */
+/* red1 fp32 [4] = (sum dq, sum dq*psihat, 0, 0), overwritten                                */
 int aau_gate_bwd1(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x_pitch,
                   const float* alpha, const float* psi_pre, const float* mean1,
                   const float* invstd1, aau_bf16* dx, int dx_pitch, float* dq, float* red1,
-                  int64_t M, int C, void* stream);
+                  int64_t M, int C, float* ws, void* stream);
 /* backward step 2: dpsi_pre = BN(1) backward of dq; ds[m,f] = dpsi_pre*wpsi[f]*[s>0];      */
-/* writes ds (bf16, masked gradient shared by both branches); dwpsi_rep [REPLICAS][F] +=     */
-/* partial sums of dpsi_pre*s (zeroed by the caller, folded into the weight gradient by     */
-/* step 3: every workgroup adding into ONE 48-float row serialised the launch);              */
-/* redg/redx [REPLICAS][2][F] += (ds, ds*zhat_g) / (ds, ds*zhat_x); dgamma1/dbeta1.         */
+/* writes ds (bf16, masked gradient shared by both branches) and tot fp32 [4][F] =          */
+/* (sum dpsi_pre*s = the psi weight gradient, sum ds, sum ds*zhat_g, sum ds*zhat_x),        */
+/* overwritten; dgamma1/dbeta1 +=.                                                          */
 int aau_gate_bwd2(const float* dq, const float* psi_pre, const float* red1, const float* gamma1,
                   const float* mean1, const float* invstd1, const aau_bf16* zg,
                   const aau_bf16* zx, const float* sg, const float* hg, const float* sx,
                   const float* hx, const float* mean_g, const float* invstd_g,
                   const float* mean_x, const float* invstd_x, const float* wpsi,
-                  aau_bf16* ds, float* dwpsi_rep, float* redg, float* redx, float* dgamma1,
-                  float* dbeta1, int64_t M, int F, void* stream);
+                  aau_bf16* ds, float* tot, float* dgamma1, float* dbeta1, int64_t M, int F,
+                  float* ws, void* stream);
 /* backward step 3: dzg/dzx from ds (BN backward without ReLU for both branches);           */
-/* dwpsi[f] += sum over replicas of dwpsi_rep (dwpsi may be NULL)                            */
+/* dwpsi[f] += tot[0][f] (dwpsi may be NULL); dgamma / dbeta of both branch BNs +=          */
 int aau_gate_bwd3(const aau_bf16* ds, const aau_bf16* zg, const aau_bf16* zx,
                   const float* gamma_g, const float* mean_g, const float* invstd_g,
-                  const float* redg, const float* gamma_x, const float* mean_x,
-                  const float* invstd_x, const float* redx, aau_bf16* dzg, aau_bf16* dzx,
+                  const float* gamma_x, const float* mean_x, const float* invstd_x,
+                  const float* tot, aau_bf16* dzg, aau_bf16* dzx,
                   float* dgamma_g, float* dbeta_g, float* dgamma_x, float* dbeta_x,
-                  const float* dwpsi_rep, float* dwpsi, int64_t M, int F, void* stream);
+                  float* dwpsi, int64_t M, int F, void* stream);
 
 /* ---- out_conv: Conv2d(C, 1, 1) with bias (pipeline:122) -------------------------------- */
 int aau_outconv_fwd(const aau_bf16* y, int y_pitch, const float* w, const float* b,
@@ -336,7 +340,8 @@ int aau_gate2_bwd(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x
 /* ---- criterion (pipeline:219-232 build_criterion with ComboLoss :187-189, DiceLoss        */
 /* :173-178, EdgeLoss :196-216) and metrics (:191-194 iou_score, :240 eval Dice) -------- */
 /* sums: fp32 [AAU_STAT_REPLICAS][B][8] workspace (zeroed by the call; [0] holds the per-   */
-/* sample sums afterwards); loss_out: fp32 [4] = total, dice,                               */
+/* sample sums afterwards; behind it the tile sums are accumulated as 64-bit fixed point:   */
+/* order-independent); loss_out: fp32 [4] = total, dice,                                    */
 /* bce, edge.  dlogits (optional, fp32 [B*H*W]) receives d(loss*loss_scale)/d(logits).       */
 int aau_criterion(const float* logits, const float* targets, float* sums, float* loss_out,
                   float* dlogits, int B, int H, int W, int finetune, float neg_bce_w,
@@ -360,7 +365,9 @@ int aau_seg_counts(const void* a, int a_is_f32, const void* b, int b_is_f32, int
                    uint64_t* out3, void* stream);
 
 /* ---- optimiser (pipeline:302 AdamW, :323 clip_grad_norm_) ------------------------------ */
-/* norm_ws: fp32 [1] zeroed by the call; accumulates sum of squares of grad*inv_scale       */
+/* norm_ws: fp32 [AAU_SQNORM_WS]; [0] = sum of squares of grad*inv_scale (workgroup partials  */
+/* in the rest, added in a fixed order: bitwise reproducible, no float atomics)              */
+#define AAU_SQNORM_WS 1028
 int aau_grad_sqnorm(const float* grad, int64_t n, float inv_scale, float* norm_ws, void* stream);
 /* p,m,v,g: flat fp32 [n].  clip coefficient = min(1, max_norm/(sqrt(norm_ws)+1e-6));       */
 /* step_dev: int64 step counter on the device, incremented by the call (bias correction).  */

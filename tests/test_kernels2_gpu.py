@@ -196,7 +196,7 @@ def test_gap_spatial_sum_colsum_broadcast(ops):
     g = torch.Generator().manual_seed(3)
     x = R.bf16_round(torch.randn(N, HW, C, generator=g))
     xd = dev(bf(x))
-    pooled, ws = zeros(N, C, dtype=torch.bfloat16), zeros(N, C)
+    pooled, ws = zeros(N, C, dtype=torch.bfloat16), torch.full((ops.GAP_WS_ROWS, N, C), float("nan"), device="cuda")
     ops.gap_fwd(xd, C, pooled, ws, N, HW, C)
     ssum = zeros(N, C, dtype=torch.bfloat16)
     ops.spatial_sum(xd, C, ssum, ws, N, HW, C)
@@ -259,18 +259,17 @@ def test_attention_gate_elementwise_forward_backward(ops, Fi, C):
     assert rel_err(wide.cpu()[:, :C], out.detach()) < 1e-2
     assert float(wide.cpu()[:, C:].abs().max()) == 0
     # backward
-    dx, dq, red1 = zeros(M, C, dtype=torch.bfloat16), zeros(M), zeros(ops.STAT_REPLICAS, 2, 1)
+    dx, dq, red1 = zeros(M, C, dtype=torch.bfloat16), zeros(M), torch.full((4,), float("nan"), device="cuda")
     ops.gate_bwd1(dev(bf(dout)), C, xd, C, al, psi_pre, sm1, si1, dx, C, dq, red1, M, C)
     ds = zeros(M, Fi, dtype=torch.bfloat16)
-    dw, redg, redx = zeros(Fi), zeros(ops.STAT_REPLICAS, 2, Fi), zeros(ops.STAT_REPLICAS, 2, Fi)
-    dwrep = zeros(ops.STAT_REPLICAS, Fi)
+    dw, tot = zeros(Fi), torch.full((4, Fi), float("nan"), device="cuda")
     dg1, db1 = zeros(1), zeros(1)
     ops.gate_bwd2(dq, psi_pre, red1, d(P["g1"]), sm1, si1, zgd, zxd, sg, hg, sx, hx, d(mg), d(ig), d(mx), d(ix),
-                  d(P["w"]), ds, dwrep, redg, redx, dg1, db1, M, Fi)
+                  d(P["w"]), ds, tot, dg1, db1, M, Fi)
     dzg, dzx = zeros(M, Fi, dtype=torch.bfloat16), zeros(M, Fi, dtype=torch.bfloat16)
     dgg, dbg, dgx, dbx = zeros(Fi), zeros(Fi), zeros(Fi), zeros(Fi)
-    ops.gate_bwd3(ds, zgd, zxd, d(P["gg"]), d(mg), d(ig), redg, d(P["gx"]), d(mx), d(ix), redx, dzg, dzx,
-                  dgg, dbg, dgx, dbx, dwrep, dw, M, Fi)
+    ops.gate_bwd3(ds, zgd, zxd, d(P["gg"]), d(mg), d(ig), d(P["gx"]), d(mx), d(ix), tot, dzg, dzx,
+                  dgg, dbg, dgx, dbx, dw, M, Fi)
     torch.cuda.synchronize()
     # the x gradient has two parts; this kernel chain produces the direct one (dout*alpha)
     assert rel_err(dx.cpu(), (dout * alpha.detach())) < 1e-2
@@ -325,7 +324,7 @@ def test_clip_and_adamw_match_torch(ops):
     pc = p0.clone().requires_grad_(True)
     opt = torch.optim.AdamW([pc], lr=3e-4, weight_decay=5e-4)
     pd, md, vd = dev(p0.clone()), zeros(n), zeros(n)
-    step, ws = torch.zeros(1, dtype=torch.int64, device="cuda"), zeros(1)
+    step, ws = torch.zeros(1, dtype=torch.int64, device="cuda"), zeros(ops.SQNORM_WS)
     for it in range(3):
         grad = torch.randn(n, generator=g) * (0.01 if it == 1 else 1.0)  # step 1 is below the clip threshold
         pc.grad = grad.clone()
@@ -335,7 +334,7 @@ def test_clip_and_adamw_match_torch(ops):
         ops.grad_sqnorm(gd, n, 1.0, ws)
         ops.adamw_step(pd, md, vd, gd, n, ws, step, 3e-4)
         torch.cuda.synchronize()
-        assert abs(float(ws.item()) ** 0.5 - float(gn)) < 1e-3 * float(gn)
+        assert abs(float(ws[0].item()) ** 0.5 - float(gn)) < 1e-3 * float(gn)
         assert float((pd.cpu() - pc.detach()).abs().max()) < 2e-6
     assert int(step.item()) == 3
     # non-finite gradients skip the step

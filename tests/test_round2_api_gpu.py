@@ -157,9 +157,10 @@ def test_graphed_step_follows_the_lr_schedule(A):
         assert 0.3 < r < 0.7, r                            # the second step ran at half the rate ...
         assert 0.8e-3 < float(d1[moved].median()) < 1.2e-3
         assert torch.equal(s[3], s[2])                     # ... and the third at lr 0 moved nothing
-    ue, ug = (e[2] - e[0]).double(), (g[2] - g[0]).double()
-    cos = float((ue * ug).sum() / (ue.norm() * ug.norm()))
-    assert cos > 0.7, cos       # same trajectory; Adam turns the run-to-run noise of tiny gradients into sign flips
+    # every sum of the step is order-independent (fixed-point statistics, rows + fold, slabs): the captured graph and the
+    # eager launch list produce the same weights bit for bit
+    for a, b in zip(e, g):
+        assert torch.equal(a, b)
 
 
 def test_parameter_groups_give_attention_its_own_rate(A):
@@ -233,3 +234,31 @@ def test_forward_is_bitwise_reproducible_in_training_mode(A):
     with torch.no_grad():
         m(xb)
     assert bool(torch.isnan(m.state_dict()["d1.0.block.1.running_mean"]).any())
+
+
+def test_training_step_is_bitwise_reproducible(A):
+    """Three full steps (forward, criterion, backward, clip, AdamW; dropout on, p = 0.1) from the same state and seed, twice:
+    identical weights, gradients, Adam moments and running statistics bit for bit.  Nothing in the step is summed with
+    float atomics: BatchNorm statistics and criterion sums are fixed-point integer adds, every other cross-workgroup
+    sum is per-workgroup rows added in a fixed order (csrc/common.h: red_fold_launch, wg_reduce_kernel)."""
+    from att_aspp_unet_amd import synth
+    args = Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05)
+    x, y = synth.make_frames(4, 128, seed=9, force_pattern="ppnp")
+    x, y = x.cuda(), y.cuda()
+
+    def run():
+        torch.manual_seed(77)
+        m = A.AttentionASPPUNet(base_c=16).cuda().train()
+        opt = A.FusedAdamW(m, lr=1e-3)
+        step = A.TrainStep(m, opt, args)
+        losses = [float(step(x, y)) for _ in range(3)]
+        st = m.engine.store
+        return losses, st.flat.clone(), st.gflat.clone(), st.m.clone(), st.v.clone(), {k: v.clone() for k, v in m.state_dict().items()}
+
+    a, b = run(), run()
+    assert a[0] == b[0], (a[0], b[0])
+    for u, v in zip(a[1:5], b[1:5]):
+        assert torch.equal(u, v)
+    for k in a[5]:
+        assert torch.equal(a[5][k], b[5][k]), k
+    assert a[0][2] < a[0][0]
