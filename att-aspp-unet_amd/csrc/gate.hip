@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256) void gate2_fwd_kernel(const unsigned short* zg
 }
 
 // dx = dout * (1 + a) (written); dpre = <dout, x> * a (1 - a); ds[f] = dpre * w[f] * [s_f > 0] (written, bf16);
-// rep[block % R][f] += dpre * s_f, rep[..][F] += dpre  (folded into dwpsi / dbpsi by the launcher)
+// every wave stores its row (sum dpre * s_f | sum dpre) [F + 8]; red_fold_launch adds the rows in a fixed order into
+// dwpsi / dbpsi
 __global__ __launch_bounds__(256) void gate2_bwd_kernel(const unsigned short* dout, int dop, const unsigned short* x, int xp,
                                                         const float* alpha, const unsigned short* zg, const unsigned short* zx,
                                                         const float* wpsi, unsigned short* dx, int dxp, unsigned short* ds,
@@ -464,11 +465,15 @@ __global__ __launch_bounds__(256) void gate2_bwd_kernel(const unsigned short* do
             *(u32x4*)(ds + m * F + lane * 8) = pack8(o);
         }
     }
-    float* r = rep + (size_t)(blockIdx.x % AAU_STAT_REPLICAS) * (F + 8);
-    if (lane < FG)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(r + lane * 8 + j, acc[j]);
-    if (lane == 0) atomicAdd(r + F, bsum);
+    float* r = red_row(rep, F + 8, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    if (lane < FG) {
+        *(f32x4*)(r + lane * 8) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *(f32x4*)(r + lane * 8 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
+    if (lane == 0) {
+        *(f32x4*)(r + F) = f32x4{bsum, 0.f, 0.f, 0.f};
+        *(f32x4*)(r + F + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 }  // namespace aau
@@ -496,13 +501,12 @@ extern "C" int aau_gate2_bwd(const aau_bf16* dout, int dout_pitch, const aau_bf1
     AAU_REQUIRE(dout_pitch % 8 == 0 && x_pitch % 8 == 0 && dx_pitch % 8 == 0, "aau_gate2_bwd: pitch");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(2, 0, s);
-    zero_f32(rep_ws, (int64_t)AAU_STAT_REPLICAS * (F + 8), s);
-    int64_t blocks = (M + 63) / 64;           // 16 pixels per wave: the per-workgroup replica atomics stay a small tail
-    if (blocks > 2048) blocks = 2048;
+    AAU_REQUIRE(((uintptr_t)rep_ws & 15) == 0, "aau_gate2_bwd: ws must be 16-byte aligned");
+    int64_t blocks = (M + 63) / 64;           // 16 pixels per wave
+    if (blocks > AAU_BN_RED_MAX_BLOCKS / 4) blocks = AAU_BN_RED_MAX_BLOCKS / 4;     // one row per wave
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gate2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dout, dout_pitch, x, x_pitch, alpha, zg, zx,
                        wpsi, dx, dx_pitch, ds, rep_ws, M, F, C);
-    if (int rc = check_launch("aau_gate2_bwd")) return rc;
-    if (int rc = aau_fold_replicas(rep_ws, F + 8, dwpsi, F, stream)) return rc;      // dwpsi[f] += sum of the replicas
-    return aau_fold_replicas(rep_ws + F, F + 8, dbpsi, 1, stream);
+    red_fold_launch(rep_ws, F + 8, (int)blocks * 4, nullptr, 0, dwpsi, F, dbpsi, s);
+    return check_launch("aau_gate2_bwd");
 }

@@ -661,7 +661,7 @@ class Plan:
                 wg, wx, psi = gt["wg"], gt["wx"], gt["psi"]
                 ds = self.new(Mo, Fi)
                 b.add("aau_gate2_bwd", dcat, 2 * Co, skips[lv], skip_p[lv], gt["alpha"], gt["zg"], gt["zx"], psi.w,
-                      dskip[lv], Co, ds, gt["rep"], psi.dw, psi.dbias, Mo, Fi, Co)
+                      dskip[lv], Co, ds, self.red_ws, psi.dw, psi.dbias, Mo, Fi, Co)
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi), cat[:, Co:], ds, wg.dw)
                 b.add_wgrad(ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi), skips[lv], ds, wx.dw)
                 sB = None if sA is None else self.bstats_arena.take(ops.stat_words(Co))

@@ -331,8 +331,8 @@ int aau_gate2_fwd(const aau_bf16* zg, const aau_bf16* zx, const float* wpsi, con
                   const aau_bf16* x, int x_pitch, float* alpha, aau_bf16* out, int out_pitch, int64_t M,
                   int F, int C, void* stream);
 /* backward: dx = dout*(1+alpha) (written); ds[m,f] = dpre*wpsi[f]*[s>0] with dpre = <dout,x>*alpha*(1-alpha)  */
-/* (the gradient of BOTH 1x1 outputs); dwpsi += sum dpre*relu(s), dbpsi += sum dpre; rep_ws fp32                */
-/* [AAU_STAT_REPLICAS][F+8]                                                                                   */
+/* (the gradient of BOTH 1x1 outputs); dwpsi += sum dpre*relu(s), dbpsi += sum dpre; rep_ws:                     */
+/* aau_bn_red_ws_bytes(F) (one row of partial sums per wave, added in a fixed order)                           */
 int aau_gate2_bwd(const aau_bf16* dout, int dout_pitch, const aau_bf16* x, int x_pitch, const float* alpha,
                   const aau_bf16* zg, const aau_bf16* zx, const float* wpsi, aau_bf16* dx, int dx_pitch,
                   aau_bf16* ds, float* rep_ws, float* dwpsi, float* dbpsi, int64_t M, int F, int C, void* stream);
