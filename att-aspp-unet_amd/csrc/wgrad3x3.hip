@@ -41,6 +41,7 @@ struct W3Args {
     int patches_per_block, nsplit;
     int tiles_x, tiles_y;        // W/16, H/8
     int rev;                     // 1: workgroups take the split ranges from the end (aau_traverse)
+    int noremap;                 // experiment (AAU_W3_NOREMAP): the round-1 order, split fastest, no XCD remap
 };
 
 // QT = 16-channel q tiles per workgroup (3: 48 channels, 6: 96 channels); PR = patch rows per K-step.
@@ -75,12 +76,22 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
     const int wc = wave & 3, grp = wave >> 2;   // column-tile wave, q group
 
     const int ntc = (d.Cin + 47) / 48;
+    // Workgroup order: the K-split (patch range) is the SLOWEST index and the bijective XCD remap (igemm.hip) gives each
+    // XCD a contiguous run of logical ids, i.e. the workgroups that share an XCD's L2 are different (q, c) tiles of the
+    // SAME patch range: they read the same x halos (once per q tile) and dz tiles (once per c tile).  With the split
+    // fastest and no remap, neighbours on an XCD shared nothing and every operand came over the fabric once per tile:
+    // 529 MB per launch of L2 misses against 115 MB algorithmic (profiles/r02_pmc_traffic.json).
     int bid = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    const int lbid = bid;      // logical workgroup id = slab index
-    const int split = bid % a.nsplit;
-    bid /= a.nsplit;
-    const int tc = bid % ntc;
-    const int tq = bid / ntc;
+    if (!a.noremap) {
+        const int nwg = (int)gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int ntile = (int)gridDim.x / a.nsplit;
+    const int split = a.noremap ? bid % a.nsplit : bid / ntile;
+    const int tile = a.noremap ? bid / a.nsplit : bid - split * ntile;
+    const int lbid = tile * a.nsplit + split;      // slab index (wg_reduce walks the splits of a tile)
+    const int tc = tile % ntc;
+    const int tq = tile / ntc;
     const int q0 = tq * BQ, c0 = tc * 48;
     const int p_begin = split * a.patches_per_block;
     const int p_end = min(a.npatch, p_begin + a.patches_per_block);
@@ -297,6 +308,7 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_by
     }
     a.ws = ws;
     a.rev = next_traversal();
+    a.noremap = getenv("AAU_W3_NOREMAP") ? 1 : 0;
     hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR, NG>), dim3((unsigned)grid), dim3(256 * NG), 0, s, a);
     if (!ws) return check_launch("aau_conv_wgrad(3x3)");
     WRedArgs r;

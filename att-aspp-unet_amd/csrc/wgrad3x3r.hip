@@ -38,6 +38,7 @@ struct W3RArgs {
     int patches_per_block, nsplit;
     int tiles_x, tiles_y;        // W/16, H/8
     int rev;
+    int noremap;                 // experiment (AAU_W3_NOREMAP): the round-1 order, split fastest, no XCD remap
 };
 
 #define AAU_TR16O(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
@@ -68,12 +69,22 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
     const int jw = wave % CJ, qg = wave / CJ;
 
     const int ntc = (d.Cin + BC - 1) / BC;
+    // Workgroup order: the K-split (patch range) is the SLOWEST index and the bijective XCD remap (igemm.hip) gives each
+    // XCD a contiguous run of logical ids, i.e. the workgroups that share an XCD's L2 are different (q, c) tiles of the
+    // SAME patch range: they read the same x halos (once per q tile) and dz tiles (once per c tile).  With the split
+    // fastest and no remap, neighbours on an XCD shared nothing and every operand came over the fabric once per tile:
+    // 529 MB per launch of L2 misses against 115 MB algorithmic (profiles/r02_pmc_traffic.json).
     int bid = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    const int lbid = bid;      // logical workgroup id = slab index
-    const int split = bid % a.nsplit;
-    bid /= a.nsplit;
-    const int tc = bid % ntc;
-    const int tq = bid / ntc;
+    if (!a.noremap) {
+        const int nwg = (int)gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int ntile = (int)gridDim.x / a.nsplit;
+    const int split = a.noremap ? bid % a.nsplit : bid / ntile;
+    const int tile = a.noremap ? bid / a.nsplit : bid - split * ntile;
+    const int lbid = tile * a.nsplit + split;      // slab index (wg_reduce walks the splits of a tile)
+    const int tc = tile % ntc;
+    const int tq = tile / ntc;
     const int q0 = tq * BQ, c0 = tc * BC;
     const int p_begin = split * a.patches_per_block;
     const int p_end = min(a.npatch, p_begin + a.patches_per_block);
@@ -260,10 +271,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
 }
 
 // Which kernel: 0 = wgrad3x3.hip (48 q x 48 c), 1 = <3,4> (48 q x 64 c), 2 = <6,2> (96 q x 32 c).  Never a shape that
-// pads more than the 48 x 48 tiling; beyond that the choice is the measured one (bs 8, base_c 48, one device, A/B in
-// the same step): the row-reuse kernels win 6-12 % where the operands are L2-resident (<= 64 x 64 pixels: d4.*, u4.*)
-// or the reduction is long against the tile count (Cin >= 2 Cout; 96 -> 96 at 256 x 256 as ONE 96-row q tile), and
-// lose 5-20 % on the 128 x 128 layers with Cin <= Cout, whose larger tiles mean more split-K slabs per FLOP.
+// pads more than the 48 x 48 tiling.  Measured per layer (bs 8, base_c 48, A/B on one device, XCD-aware workgroup
+// order): <6,2> is the fastest or tied wherever it fits (Cout % 96 == 0, Cin % 32 == 0: -10...20 % against wgrad3x3 on
+// d2.1, d3.*, d4.*, u2-u4), <3,4> where only it fits; the 48-channel layers of level 1 keep wgrad3x3.
 int wgrad3x3r_variant(const aau_conv_desc* d) {
     if (getenv("AAU_W3_NOR")) return 0;
     if (const char* e = getenv("AAU_W3_R")) return atoi(e);          // experiment: force a variant
@@ -271,9 +281,8 @@ int wgrad3x3r_variant(const aau_conv_desc* d) {
         return (double)d->Cout / ((d->Cout + bq - 1) / bq * bq) * (double)d->Cin / ((d->Cin + bc - 1) / bc * bc);
     };
     const double e0 = eff(48, 48), e1 = eff(48, 64), e2 = eff(96, 32);
-    const int64_t npix = (int64_t)d->N * d->H * d->W;
-    if (e1 >= 0.99 * e0 && (npix <= 8 * 64 * 64 || d->Cin >= 2 * d->Cout)) return 1;
-    if (e2 >= 0.99 * e0 && d->Cout <= 96 && d->Cin <= 96) return 2;
+    if (e2 >= 0.99 * e0) return 2;
+    if (e1 >= 0.99 * e0) return 1;
     return 0;
 }
 
@@ -305,6 +314,7 @@ static int launch_w3r(W3RArgs& a, const aau_conv_desc* d, float* ws, int64_t ws_
     }
     a.ws = ws;
     a.rev = next_traversal();
+    a.noremap = getenv("AAU_W3_NOREMAP") ? 1 : 0;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void*)wgrad3x3r_kernel<QT, CJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
