@@ -80,10 +80,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int T = d.KH * d.KW;
     const int ntq = (d.Cout + 48 * TQ - 1) / (48 * TQ);
     const int ntc = (d.Cin + 48 * TC - 1) / (48 * TC);
+    // K-split slowest + bijective XCD remap: the workgroups of one XCD are different (q, c, tap) tiles of the SAME pixel
+    // range, so they share their dz / x rows in that XCD's L2 (see wgrad3x3r.hip)
     int bid = a.rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    const int lbid = bid;      // logical workgroup id = slab index
-    const int split = bid % a.nsplit;
-    bid /= a.nsplit;
+    {
+        const int nwg = (int)gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int ntile = (int)gridDim.x / a.nsplit;
+    const int split = bid / ntile;
+    bid -= split * ntile;
+    const int lbid = bid * a.nsplit + split;      // slab index (wg_reduce walks the splits of a tile)
     const int tap = bid % T;
     bid /= T;
     const int tc = bid % ntc;
