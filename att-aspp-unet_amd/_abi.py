@@ -27,7 +27,8 @@ class ConvDesc(C.Structure):
     """``aau_conv_desc`` (include/aau.h)."""
     _fields_ = [(n, C.c_int32) for n in (
         "N", "H", "W", "Cin", "src_pitch", "Ho", "Wo", "Cout", "dst_pitch", "KH", "KW",
-        "stride", "pad", "dil", "Cpad", "shuffle2x2", "accumulate", "relu")]
+        "stride", "pad", "dil", "Cpad", "shuffle2x2", "accumulate", "relu",
+        "src_split_c", "src_split_off", "dst_split_c", "dst_split_off")]
 
 
 class PackEntry(C.Structure):
@@ -54,6 +55,7 @@ _SIGS = {
     "aau_conv_is_halo3x3": [C.POINTER(ConvDesc)],
     "aau_traverse": [I],
     "aau_conv_wgrad": [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P],
+    "aau_conv_split_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_wgrad_ws_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int64)],
     "aau_conv_wgrad_group_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_wgrad_group": [C.POINTER(ConvDesc), P, P, P, I, P],

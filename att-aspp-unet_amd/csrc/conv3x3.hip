@@ -1129,6 +1129,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
         htail[i] = tail_c0 + lc_[i] * 8 < d.Cin;
     }
     const bool has_tail = d.Cpad != d.Cin;
+    const int split_c = d.src_split_c > 0 ? d.src_split_c : 0x7fffffff;
+    const int split_adj = d.src_split_off - d.src_split_c;           // elements
+    const int dsplit_c = d.dst_split_c > 0 ? d.dst_split_c : 0x7fffffff;
+    const int dsplit_adj = d.dst_split_off - d.dst_split_c;
     auto patch_origin = [&](int patch, int& n, int& y0, int& x0) {
         if (a.rev) patch = npatch - 1 - patch;
         const int px_t = patch % a.tiles_x;
@@ -1144,7 +1148,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
         for (int i = 0; i < HL; ++i) {
             const int y = y0 - 1 + hy_[i], x = x0 - 1 + hx_[i];
             const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
-            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;
+            // two-plane source (aau.h): this lane's 8 channels of the chunk may live in the second plane
+            const int sadj = (chunk * BK + lc_[i] * 8 >= split_c) ? split_adj : 0;
+            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8 + sadj) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * NW + wave) * 16 * BK), 16, (int)v,
                                                      chunk * BK * 2, 0, 0);
         }
@@ -1246,7 +1252,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
                 u32x2 pk;
                 pk[0] = pack2(v[0], v[1]);
                 pk[1] = pack2(v[2], v[3]);
-                *(u32x2*)(a.dst + pixel * d.dst_pitch + q) = pk;
+                *(u32x2*)(a.dst + pixel * d.dst_pitch + q + (q >= dsplit_c ? dsplit_adj : 0)) = pk;
             }
         }
     }
@@ -1742,6 +1748,19 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     return check_launch("aau_conv_igemm(1x1 resident weights)");
 }
 
+// true when conv3x3_launch would take the (single patch stream) resident-weight kernel, the one that serves two-plane
+// operands
+bool conv3x3_split_ok(const aau_conv_desc* d) {
+    const bool narrow = d->Cout <= 48;
+    const int BQ = narrow ? 48 : 96;
+    const int nchunk = d->Cpad / 32;
+    const int npatch = (d->W / 16) * (d->H / 16) * d->N;
+    const size_t wbytes = ((size_t)nchunk * 9 * BQ * 64 + 8191) / 8192 * 8192;
+    const size_t lds = (size_t)2 * 384 * 64 + wbytes;
+    const int ntq = (d->Cout + BQ - 1) / BQ;
+    return !d->accumulate && lds <= 160 * 1024 && npatch >= 1024 && ntq <= 2;
+}
+
 // true when the halo kernel applies to this descriptor
 bool conv3x3_applicable(const aau_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->dil == 1 && !d->shuffle2x2 &&
@@ -1775,7 +1794,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
             const size_t lds2 = (size_t)4 * 384 * 64 + wb2;
             const int gx2 = npatch / 2 < 256 ? npatch / 2 : 256;
             if (narrow && ntq == 1 && !d->accumulate && lds2 <= 160 * 1024 && npatch >= 2048 && npatch % (2 * gx2) == 0 &&
-                !getenv("AAU_NO_RESW") && !getenv("AAU_NO_RESW2")) {
+                d->src_split_c <= 0 && d->dst_split_c <= 0 && !getenv("AAU_NO_RESW") && !getenv("AAU_NO_RESW2")) {
                 static bool attr2 = false;
                 if (!attr2) {
                     hipFuncSetAttribute((const void*)conv3x3_resw2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1786,7 +1805,8 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                 return check_launch("aau_conv_igemm(3x3 resident weights, two patch streams)");
             }
         }
-        if (!d->accumulate && lds <= 160 * 1024 && npatch >= 1024 && ntq <= 2 && !getenv("AAU_NO_RESW")) {
+        const bool split = d->src_split_c > 0 || d->dst_split_c > 0;
+        if (!d->accumulate && lds <= 160 * 1024 && npatch >= 1024 && ntq <= 2 && (split || !getenv("AAU_NO_RESW"))) {
             static bool attr48 = false, attr96 = false;
             if (narrow && !attr48) {
                 hipFuncSetAttribute((const void*)conv3x3_resw_kernel<48, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1808,6 +1828,10 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
             else hipLaunchKernelGGL((conv3x3_resw_kernel<96, 4>), dim3(gx, ntq), dim3(256), lds, s, a, npatch);
             return check_launch("aau_conv_igemm(3x3 resident weights)");
         }
+    }
+    if (d->src_split_c > 0 || d->dst_split_c > 0) {
+        set_error("aau_conv_igemm: two-plane operands are only served by the resident-weight 3x3 kernel (aau_conv_split_ok)");
+        return AAU_E_INVALID;
     }
     // 16 x 32 patches with 8 waves (one workgroup per CU) halve the LDS-DMA instructions per wave, but
     // measured 8-12 % SLOWER than two 4-wave workgroups per CU (A/B on one device): opt-in only

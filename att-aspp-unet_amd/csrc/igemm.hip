@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
 // conv3x3.hip
 bool conv3x3_applicable(const aau_conv_desc* d);
+bool conv3x3_split_ok(const aau_conv_desc* d);
 int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
                    const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
                    hipStream_t s);
@@ -393,7 +394,10 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
     AAU_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0, "aau_conv_igemm: Cin=%d must be a positive multiple of 8", d->Cin);
     AAU_REQUIRE(d->Cout > 0 && d->Cout % 8 == 0, "aau_conv_igemm: Cout=%d must be a positive multiple of 8", d->Cout);
     AAU_REQUIRE(d->Cpad >= d->Cin && d->Cpad % 32 == 0, "aau_conv_igemm: Cpad=%d must be a multiple of 32 >= Cin", d->Cpad);
-    AAU_REQUIRE(d->src_pitch >= d->Cin && d->src_pitch % 8 == 0, "aau_conv_igemm: src_pitch=%d", d->src_pitch);
+    {   // a pixel's channels fit in its row (each plane's share when the source has two planes)
+        const int row_c = d->src_split_c > 0 ? (d->src_split_c > d->Cin - d->src_split_c ? d->src_split_c : d->Cin - d->src_split_c) : d->Cin;
+        AAU_REQUIRE(d->src_pitch >= row_c && d->src_pitch % 8 == 0, "aau_conv_igemm: src_pitch=%d", d->src_pitch);
+    }
     AAU_REQUIRE(d->dst_pitch % 4 == 0, "aau_conv_igemm: dst_pitch=%d must be a multiple of 4", d->dst_pitch);
     AAU_REQUIRE(d->KH >= 1 && d->KW >= 1 && d->KH * d->KW <= 16, "aau_conv_igemm: taps %dx%d", d->KH, d->KW);
     AAU_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "aau_conv_igemm: empty shape");
@@ -410,7 +414,16 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
     a.d = *d;
     a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
     a.M = d->N * d->Ho * d->Wo;
-    const int64_t src_bytes = (((int64_t)d->N * d->H * d->W - 1) * d->src_pitch + d->Cin) * 2;
+    const bool split = d->src_split_c > 0 || d->dst_split_c > 0;
+    if (split) {
+        AAU_REQUIRE(conv3x3_applicable(d) && conv3x3_split_ok(d),
+                    "aau_conv_igemm: two-plane operands are only served by the resident-weight 3x3 kernel (aau_conv_split_ok)");
+        AAU_REQUIRE(d->src_split_c % 8 == 0 && d->src_split_c < d->Cin && d->src_split_off % 8 == 0 && d->src_split_off >= 0 &&
+                        d->dst_split_c % 4 == 0 && d->dst_split_c < d->Cout && d->dst_split_off % 4 == 0 && d->dst_split_off >= 0,
+                    "aau_conv_igemm: split_c / split_off must be aligned (8 source, 4 destination elements) and inside the channel range");
+    }
+    const int64_t src_bytes = (((int64_t)d->N * d->H * d->W - 1) * d->src_pitch + d->Cin +
+                               (d->src_split_c > 0 ? d->src_split_off - d->src_split_c : 0)) * 2;
     const int64_t wpk_bytes = (int64_t)d->Cout * d->KH * d->KW * d->Cpad * 2;
     AAU_REQUIRE(src_bytes < 0x7fffffff && wpk_bytes < 0x7fffffff,
                 "aau_conv_igemm: source (%lld B) / packed weights (%lld B) must stay below 2 GiB", (long long)src_bytes,
@@ -442,6 +455,15 @@ extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const
                               aau_bf16* dst, const float* bias, const float* scale, const float* shift,
                               aau_stat* stats, void* stream) {
     return conv_dispatch(d, src, wpk, dst, bias, scale, shift, (float*)stats, stream);
+}
+
+// wgrad3x3.hip
+namespace aau { bool wgrad3x3_applicable(const aau_conv_desc* d); }
+
+extern "C" int aau_conv_split_ok(const aau_conv_desc* d, int mode) {
+    if (!d) return 0;
+    if (mode == 0) return aau::conv3x3_applicable(d) && aau::conv3x3_split_ok(d) ? 1 : 0;
+    return aau::wgrad3x3_applicable(d) && d->dst_split_c <= 0 ? 1 : 0;
 }
 
 extern "C" int aau_conv_is_halo3x3(const aau_conv_desc* d) {

@@ -463,8 +463,14 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
     a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
     a.M = d->N * d->Ho * d->Wo;
     a.linear = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo);
+    const bool split = d->src_split_c > 0 || d->dst_split_c > 0;
+    if (split) {
+        AAU_REQUIRE(wgrad3x3_applicable(d) && d->dst_split_c <= 0, "aau_conv_wgrad: a two-plane source is only served by the all-taps 3x3 kernel (aau_conv_split_ok)");
+        AAU_REQUIRE(d->src_split_c % 8 == 0 && d->src_split_c < d->Cin && d->src_split_off % 8 == 0 && d->src_split_off >= 0,
+                    "aau_conv_wgrad: src_split_c / src_split_off must be multiples of 8 inside the channel range");
+    }
     if (wgrad3x3_applicable(d)) {
-        const int rv = wgrad3x3r_variant(d);
+        const int rv = split ? 0 : wgrad3x3r_variant(d);
         if (need) return rv ? wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream)
                             : wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream);
         const double flops = 2.0 * a.M * (double)d->Cout * d->Cin * d->KH * d->KW;

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
         xhy[i] = (px < XROWS && c0 + s * 8 < d.Cin) ? hy : -100000;
         xhx[i] = hx;
         xch[i] = c0 + s * 8;
+        if (d.src_split_c > 0 && xch[i] >= d.src_split_c) xch[i] += d.src_split_off - d.src_split_c;   // second plane (aau.h)
     }
 
     auto stage = [&](int buf, int patch) {
@@ -325,7 +326,8 @@ int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16*
     a.d = *d;
     a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
     const int64_t npix = (int64_t)d->N * d->H * d->W;
-    const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin) * 2, zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
+    const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin + (d->src_split_c > 0 ? d->src_split_off - d->src_split_c : 0)) * 2;
+    const int64_t zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
     if (sb >= 0x7fffffff || zb >= 0x7fffffff) { set_error("aau_conv_wgrad: tensors must stay below 2 GiB"); return AAU_E_INVALID; }
     a.src_bytes = (unsigned)sb;
     a.dz_bytes = (unsigned)zb;

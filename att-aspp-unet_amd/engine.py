@@ -358,6 +358,26 @@ class Plan:
         self.bwd.bind_wgrad_ws(self.dev)
 
     # ---- small helpers ----
+    def _planar_ok(self, lv, gate_kind, B, h, w, Co, train) -> bool:
+        """Two-plane concat at this level: ungated, and every consumer launch serves two-plane operands."""
+        import os
+        if gate_kind is not None or os.environ.get("AAU_NO_PLANAR", "0") == "1":
+            return False
+        st = self.eng.store
+        cv = st.convs[f"u{lv + 1}.conv.0.block.0"]
+        M = B * h * w
+        if 2 * M * Co >= 1 << 30:
+            return False
+        fwd = ops.conv_desc(B, h, w, 2 * Co, Co, h, w, Co, Co, 3, 3, 1, 1, 1, cv.cpad_f, src_split=(Co, M * Co))
+        if not ops.conv_split_ok(fwd, 0):
+            return False
+        if train:
+            dg = ops.conv_desc(B, h, w, Co, Co, h, w, 2 * Co, Co, 3, 3, 1, 1, 1, cv.cpad_d, dst_split=(Co, M * Co))
+            wg = ops.conv_desc(B, h, w, 2 * Co, Co, h, w, Co, Co, 3, 3, 1, 1, 1, src_split=(Co, M * Co))
+            if not (ops.conv_split_ok(dg, 0) and ops.conv_split_ok(wg, 1)):
+                return False
+        return True
+
     def new(self, *shape, dtype=None):
         dtype = self.eng.adt if dtype is None else dtype
         return torch.zeros(*shape, dtype=dtype, device=self.dev)
@@ -375,7 +395,8 @@ class Plan:
         self.fwd.add("aau_bn_fold_eval", bn.gamma, bn.beta, bn.rm, bn.rv, w["scale"], w["shift"], bn.C, 1e-5)
 
     # ---- ConvBNReLU on MFMA: forward ----
-    def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0, pool=None, head=None):
+    def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0, pool=None, head=None,
+                src_split=(0, 0)):
         """conv(cname) -> BN(bname) -> ReLU; returns the per-layer record used by the backward.
         ``head`` (training only): the out_conv ConvP when this is the last ConvBNReLU -- its activation feeds out_conv
         alone, so BN + ReLU + out_conv run as one pass and neither the activation nor its gradient is stored."""
@@ -385,10 +406,12 @@ class Plan:
         M = N * H * W
         pad = cv.dil * (cv.k // 2)
         w = self.bnbuf(bn.C)
-        rec = dict(cv=cv, bn=bn, w=w, N=N, H=H, W=W, M=M, src=src, sp=sp, drop=drop, bcast_hw=bcast_hw)
+        rec = dict(cv=cv, bn=bn, w=w, N=N, H=H, W=W, M=M, src=src, sp=sp, drop=drop, bcast_hw=bcast_hw,
+                   src_split=src_split)
         if self.train:
             z = self.new(M, cv.O)
-            d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f)
+            d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f,
+                              src_split=src_split)
             self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
             self._bn_finalize(bn, w, M)
             Mo = M * bcast_hw if bcast_hw else M
@@ -410,7 +433,8 @@ class Plan:
                 self.fwd.add("aau_bn_act", z, cv.O, ydst, yp, w["scale"], w["shift"], M * bcast_hw, cv.O, 1,
                              bcast_hw, 0.0, self.drop_seed)
             else:
-                d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, yp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f, relu=1)
+                d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, yp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f, relu=1,
+                                  src_split=src_split)
                 self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, ydst, None, w["scale"], w["shift"], None)
                 if pool is not None:
                     self.fwd.add("aau_maxpool2", ydst, yp, pool, cv.O, N, H, W, cv.O)
@@ -418,7 +442,7 @@ class Plan:
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
     def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, din_stats=None,
-                defer_wgrad=None):
+                defer_wgrad=None, din_split=(0, 0)):
         cv, bn, w = r["cv"], r["bn"], r["w"]
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
@@ -460,14 +484,15 @@ class Plan:
         if cv.kind == "first":
             b.add("aau_conv1_wgrad", r["src"], dz, cv.dw, N, H, W, cv.O, side=ov)
             return dz
-        dwd = ops.conv_desc(N, H, W, cv.I, r["sp"], H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil)
+        dwd = ops.conv_desc(N, H, W, cv.I, r["sp"], H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil,
+                            src_split=r.get("src_split", (0, 0)))
         if defer_wgrad is not None:
             defer_wgrad.append((dwd, r["src"], dz, cv.dw, b.label))     # emitted later as one grouped launch
         else:
             b.add_wgrad(dwd, r["src"], dz, cv.dw, side=ov)
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
-                               accumulate=accumulate)
+                               accumulate=accumulate, dst_split=din_split)
             # din_stats: [R][2][Cin] sums of the produced gradient (channel sums feed the ConvTranspose bias grad)
             b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, din_stats)
         return dz
@@ -491,10 +516,22 @@ class Plan:
         # an up-block WITHOUT a gate concatenates the encoder output as is: the encoder then writes its output straight
         # into the lower half of that block's concat buffer (u1 always; u2..u4 of the ablation variant without attention)
         gate_kinds = [eng.gate_kind(f"u{lv + 1}") for lv in range(4)]
-        cats = [self.new(Ms[lv], 2 * Cs[lv]) for lv in range(4)]
-        cat1 = cats[0]
-        skips = [cats[lv] if gate_kinds[lv] is None else self.new(Ms[lv], Cs[lv]) for lv in range(4)]
-        skip_p = [2 * Cs[lv] if gate_kinds[lv] is None else Cs[lv] for lv in range(4)]
+        # Concat buffers torch.cat([skip, up], 1) (pipeline:108).  Interleaved [M][2C] by default; an ungated level whose
+        # consumer kernels take two-plane operands (aau.h, aau_conv_split_ok) keeps TWO DENSE PLANES [2][M][C] instead:
+        # at C = 48 the 96-byte half rows at a 192-byte pitch cost their writers 2x and their readers 1.5x per byte
+        # (scripts/bench_pitch.py) -- the encoder output, the transposed conv and their gradients at level 1.
+        planar = [self._planar_ok(lv, gate_kinds[lv], B, Hs[lv], Ws[lv], Cs[lv], tr) for lv in range(4)]
+        cats = [self.new(2, Ms[lv], Cs[lv]) if planar[lv] else self.new(Ms[lv], 2 * Cs[lv]) for lv in range(4)]
+        cat_p = [Cs[lv] if planar[lv] else 2 * Cs[lv] for lv in range(4)]            # pixel pitch of either half
+        cat_split = [(Cs[lv], Ms[lv] * Cs[lv]) if planar[lv] else (0, 0) for lv in range(4)]
+
+        def lo(buf, lv):
+            return buf[0] if planar[lv] else buf
+
+        def hi_(buf, lv):
+            return buf[1] if planar[lv] else buf[:, Cs[lv]:]
+        skips = [lo(cats[lv], lv) if gate_kinds[lv] is None else self.new(Ms[lv], Cs[lv]) for lv in range(4)]
+        skip_p = [cat_p[lv] if gate_kinds[lv] is None else Cs[lv] for lv in range(4)]
         pools = [self.new(Ms[i + 1], Cs[i]) for i in range(4)]
         enc = []  # (rec0, rec1) per level
         # d1.0: direct kernel on the fp32 frame
@@ -522,7 +559,7 @@ class Plan:
                 self._bn_fold(bn0, w0)
             f.add("aau_conv1_bn_act", self.x, cv0.w, y10, c, w0["scale"], w0["shift"], B, H, W, c)
         r10["z"] = z10
-        r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, cat1, 2 * c, pool=pools[0])
+        r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, skips[0], skip_p[0], pool=pools[0])
         enc.append((r10, r11))
         for lv in range(1, 4):
             h, w_ = Hs[lv], Ws[lv]
@@ -566,9 +603,9 @@ class Plan:
             up = st.convs[f"{name}.up"]
             cat = cats[lv]
             kind = gate_kinds[lv]
-            dup = ops.conv_desc(B, hi, wi, g_c, g_c, hi, wi, 4 * Co, 2 * Co, Cpad=up.cpad_f, shuffle2x2=1)
+            dup = ops.conv_desc(B, hi, wi, g_c, g_c, hi, wi, 4 * Co, cat_p[lv], Cpad=up.cpad_f, shuffle2x2=1)
             f.label = f"{name}.up"
-            f.add("aau_conv_igemm", dup, g_in, up.pk_f, cat[:, Co:], up.bias, None, None, None)
+            f.add("aau_conv_igemm", dup, g_in, up.pk_f, hi_(cat, lv), up.bias, None, None, None)
             gate = None
             if kind == "res":
                 wg, wx, psi = st.convs[f"{name}.att.Wg"], st.convs[f"{name}.att.Wx"], st.convs[f"{name}.att.psi.1"]
@@ -616,7 +653,8 @@ class Plan:
                             psi_pre=psi_pre, alpha=alpha, Fi=Fi,
                             wrep=self.red_arena.take(STAT_REPLICAS * Fi) if tr else None)
             ya = self.new(Mo, Co)
-            ra = self.cbr_fwd(f"{name}.conv.0.block.0", f"{name}.conv.0.block.1", cat, 2 * Co, B, ho, wo, ya, Co)
+            ra = self.cbr_fwd(f"{name}.conv.0.block.0", f"{name}.conv.0.block.1", cat, cat_p[lv], B, ho, wo, ya, Co,
+                              src_split=cat_split[lv])
             fuse_head = tr and lv == 0 and not eng.no_fuse_head
             yb = None if fuse_head else self.new(Mo, Co)
             rb = self.cbr_fwd(f"{name}.conv.1.block.0", f"{name}.conv.1.block.1", ya, Co, B, ho, wo, yb, Co,
@@ -643,17 +681,18 @@ class Plan:
             b.add("aau_outconv_bwd", g_in, c, self.dlogits, oc.w, dy, c, oc.dw, oc.dbias, rep_ws, Ms[0], c)
         # gradient of the encoder outputs: its own buffer behind a gate, the lower half of dcat otherwise
         dskip = [None if gate_kinds[lv] is None else self.new(Ms[lv], Cs[lv]) for lv in range(4)]
-        dskip_p = [2 * Cs[lv] if gate_kinds[lv] is None else Cs[lv] for lv in range(4)]
+        dskip_p = [cat_p[lv] if gate_kinds[lv] is None else Cs[lv] for lv in range(4)]
         for blk in reversed(dec):            # u1, u2, u3, u4
             lv, Co, Mo, ho, wo, hi, wi = blk["lv"], blk["Co"], blk["Mo"], blk["ho"], blk["wo"], blk["hi"], blk["wi"]
             dya = self.new(Mo, Co)
             self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co)
-            dcat = self.new(Mo, 2 * Co)
+            dcat = self.new(2, Mo, Co) if planar[lv] else self.new(Mo, 2 * Co)
+            dcat_hi = hi_(dcat, lv)                # gradient of the transposed conv's output, pixel pitch cat_p[lv]
             # channel sums of dcat (fp32, from the data-gradient epilogue) -> ConvTranspose2d bias gradient below
             sA = None if eng.no_fuse_colsum else self.bstats_arena.take(ops.stat_words(2 * Co))
-            self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=2 * Co, din_stats=sA)
+            self.cbr_bwd(blk["ra"], dya, Co, din=dcat, dinp=cat_p[lv], din_stats=sA, din_split=cat_split[lv])
             if gate_kinds[lv] is None:
-                dskip[lv] = dcat
+                dskip[lv] = lo(dcat, lv)
             cat, gt, up = blk["cat"], blk["gate"], blk["up"]
             if gt is not None and gt["kind"] == "res":
                 b.label = f"{blk['name']}.att"
@@ -702,7 +741,7 @@ class Plan:
             gsrc, gc = blk["g_in"], blk["g_c"]
             b.label = f"{blk['name']}.up"
             if sA is None:
-                b.add("aau_colsum", dcat[:, Co:], 2 * Co, up.dbias, rep_ws, Mo, Co)
+                b.add("aau_colsum", dcat_hi, cat_p[lv], up.dbias, rep_ws, Mo, Co)
             else:
                 b.add("aau_fold_stats", sA, 2 * Co, 0, Co, Co, up.dbias)      # channel sums of dcat[:, Co:]
                 if gt is not None:
@@ -710,11 +749,11 @@ class Plan:
             ov = eng.overlap_wgrad
             if ov:
                 b.fork()        # dcat[:, Co:] is final (gate data-gradient accumulated above)
-            b.add_wgrad(ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1), dcat[:, Co:], gsrc, up.dw,
+            b.add_wgrad(ops.conv_desc(B, ho, wo, Co, cat_p[lv], hi, wi, gc, gc, 2, 2, 2, 0, 1), dcat_hi, gsrc, up.dw,
                         side=ov)
             dg_in = self.new(B * hi * wi, gc)
-            b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Co, 2 * Co, hi, wi, gc, gc, 2, 2, 2, 0, 1, up.cpad_d),
-                  dcat[:, Co:], up.pk_d, dg_in, None, None, None, None)
+            b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Co, cat_p[lv], hi, wi, gc, gc, 2, 2, 2, 0, 1, up.cpad_d),
+                  dcat_hi, up.pk_d, dg_in, None, None, None, None)
             dy = dg_in
             mark(blk["name"])
         # bridge

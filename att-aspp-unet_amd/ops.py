@@ -83,11 +83,17 @@ def cpad_of(cin: int) -> int:
 
 
 def conv_desc(N, H, W, Cin, src_pitch, Ho, Wo, Cout, dst_pitch, KH=1, KW=1, stride=1, pad=0, dil=1,
-              Cpad=None, shuffle2x2=0, accumulate=0, relu=0) -> ConvDesc:
+              Cpad=None, shuffle2x2=0, accumulate=0, relu=0, src_split=(0, 0), dst_split=(0, 0)) -> ConvDesc:
+    """``src_split`` / ``dst_split`` = (split_c, split_off): channels >= split_c live in a second dense plane, element
+    offset split_off from the base (aau.h: two-plane operands)."""
     if Cpad is None:
         Cpad = cpad_of(Cin)
     return ConvDesc(N, H, W, Cin, src_pitch, Ho, Wo, Cout, dst_pitch, KH, KW, stride, pad, dil, Cpad,
-                    shuffle2x2, accumulate, relu)
+                    shuffle2x2, accumulate, relu, src_split[0], src_split[1], dst_split[0], dst_split[1])
+
+
+def conv_split_ok(desc: ConvDesc, mode: int) -> bool:
+    return bool(fn("aau_conv_split_ok")(C.byref(desc), mode))
 
 
 def conv_igemm(desc: ConvDesc, src, wpk, dst, bias=None, scale=None, shift=None, stats=None):

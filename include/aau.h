@@ -90,6 +90,13 @@ typedef struct aau_conv_desc {
                             /*    GEMM writes destination pixel (2y+dy, 2x+dx), co      */
     int32_t accumulate;     /* 1: dst += result (read-modify-write, bf16)               */
     int32_t relu;           /* 1: clamp at 0 after the affine epilogue                  */
+    /* Two-plane ("planar concat") operands: channels [split_c, C) of a pixel live in a second */
+    /* dense plane, element offset split_off from the base, same pixel pitch.  0 = one plane.   */
+    /* torch.cat([skip, up], 1) of the decoder (pipeline:108) at level 1 is kept as two dense   */
+    /* [M][Co] planes: 96-byte half rows at a 192-byte pitch cost 1.5-2x per byte on gfx950      */
+    /* (scripts/bench_pitch.py).  Only the kernels aau_conv_split_ok() names take them.          */
+    int32_t src_split_c, src_split_off;
+    int32_t dst_split_c, dst_split_off;
 } aau_conv_desc;
 
 /* dst[m][q] = epi( sum_{t,c} src[gather(m,t)][c] * wpk[q][t][c] )                      */
@@ -103,6 +110,12 @@ typedef struct aau_conv_desc {
 int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
                    aau_bf16* dst, const float* bias, const float* scale, const float* shift,
                    aau_stat* stats, void* stream);
+
+/* 1 when the launch this descriptor selects supports its two-plane operands (src_split_c /  */
+/* dst_split_c): mode 0 = aau_conv_igemm (the resident-weight 3x3 kernels), 1 = aau_conv_wgrad */
+/* (wgrad3x3).  A descriptor with split operands that the selected kernel cannot serve fails   */
+/* loudly in the call itself.                                                                  */
+int aau_conv_split_ok(const aau_conv_desc* d, int mode);
 
 /* 1 when the halo-tiled 3x3 kernels (csrc/conv3x3.hip) serve this descriptor: 3x3, pad 1,   */
 /* stride 1, H and W multiples of 16, no accumulate.                                         */

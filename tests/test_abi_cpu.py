@@ -23,7 +23,13 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     from att_aspp_unet_amd import _abi
-    assert ctypes.sizeof(_abi.ConvDesc) == 18 * 4
+    assert ctypes.sizeof(_abi.ConvDesc) == 22 * 4
+    import re
+    hdr = open(_abi.HEADER).read()
+    body = hdr[hdr.index("typedef struct aau_conv_desc {"):hdr.index("} aau_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip() for decl in re.findall(r"int32_t ([^;]+);", body) for n in decl.split(",")]
+    assert names == [f[0] for f in _abi.ConvDesc._fields_]
     assert ctypes.sizeof(_abi.PackEntry) == 8 + 8 + 10 * 4 + 8
 
 

@@ -400,3 +400,57 @@ def test_wgrad_group_at_the_real_bridge_shape(ops):
     probs.append(_group_problem(ops, N, H, W, 5 * Co, Co, 1, 1, 20))
     assert ops.conv_wgrad_group_ok([p["d"] for p in probs])
     _check_group(ops, probs)
+
+
+# ---- two-plane ("planar concat") operands (aau.h: src_split_c / dst_split_c) ----
+def test_two_plane_operands_equal_the_interleaved_form(ops):
+    """u1.conv.0 of the decoder at level 1 (pipeline:108-109): its input cat([skip, up]) and the gradient of that cat are
+    kept as two dense [M][48] planes.  Forward, data-gradient (two-plane destination) and weight-gradient (two-plane
+    source) give bit-identical results to the interleaved [M][96] layout."""
+    N, H, W, Cs, Co = 4, 256, 256, 48, 48
+    M = N * H * W
+    g = torch.Generator().manual_seed(5)
+    cat = torch.randn(M, 2 * Cs, generator=g).to(torch.bfloat16).cuda()
+    planes = torch.stack([cat[:, :Cs], cat[:, Cs:]]).contiguous()                 # [2][M][Cs]
+    w = R.bf16_round(torch.randn(Co, 2 * Cs, 3, 3, generator=g) / (2 * Cs * 9) ** 0.5)
+    cp = ops.cpad_of(2 * Cs)
+    wp = dev(pack_fwd(w, cp))
+    # forward
+    d_i = ops.conv_desc(N, H, W, 2 * Cs, 2 * Cs, H, W, Co, Co, 3, 3, 1, 1, 1, cp)
+    d_p = ops.conv_desc(N, H, W, 2 * Cs, Cs, H, W, Co, Co, 3, 3, 1, 1, 1, cp, src_split=(Cs, M * Cs))
+    assert ops.conv_split_ok(d_p, 0)
+    out_i, out_p = (torch.empty(M, Co, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    st_i, st_p = ops.stats_buffer(Co), ops.stats_buffer(Co)
+    ops.conv_igemm(d_i, cat, wp, out_i, stats=st_i)
+    ops.conv_igemm(d_p, planes, wp, out_p, stats=st_p)
+    torch.cuda.synchronize()
+    assert torch.equal(out_i, out_p) and torch.equal(st_i, st_p)
+    # data gradient: 48 -> 96 channels, destination in two planes
+    dz = torch.randn(M, Co, generator=g).to(torch.bfloat16).cuda()
+    cpd = ops.cpad_of(Co)
+    wd = dev(pack_dgrad(w, cpd))
+    dd_i = ops.conv_desc(N, H, W, Co, Co, H, W, 2 * Cs, 2 * Cs, 3, 3, 1, 1, 1, cpd)
+    dd_p = ops.conv_desc(N, H, W, Co, Co, H, W, 2 * Cs, Cs, 3, 3, 1, 1, 1, cpd, dst_split=(Cs, M * Cs))
+    assert ops.conv_split_ok(dd_p, 0)
+    din_i = torch.empty(M, 2 * Cs, dtype=torch.bfloat16, device="cuda")
+    din_p = torch.empty(2, M, Cs, dtype=torch.bfloat16, device="cuda")
+    sa, sb = ops.stats_buffer(2 * Cs), ops.stats_buffer(2 * Cs)
+    ops.conv_igemm(dd_i, dz, wd, din_i, stats=sa)
+    ops.conv_igemm(dd_p, dz, wd, din_p, stats=sb)
+    torch.cuda.synchronize()
+    assert torch.equal(din_p[0], din_i[:, :Cs]) and torch.equal(din_p[1], din_i[:, Cs:]) and torch.equal(sa, sb)
+    # weight gradient with a two-plane source
+    dw_i = torch.zeros(Co, 9, 2 * Cs, device="cuda")
+    dw_p = torch.zeros_like(dw_i)
+    wi = ops.conv_desc(N, H, W, 2 * Cs, 2 * Cs, H, W, Co, Co, 3, 3, 1, 1, 1)
+    wpd = ops.conv_desc(N, H, W, 2 * Cs, Cs, H, W, Co, Co, 3, 3, 1, 1, 1, src_split=(Cs, M * Cs))
+    assert ops.conv_split_ok(wpd, 1)
+    ops.conv_wgrad(wi, cat, dz, dw_i, _wgrad_ws(ops, wi, "slab"))
+    ops.conv_wgrad(wpd, planes, dz, dw_p, _wgrad_ws(ops, wpd, "slab"))
+    torch.cuda.synchronize()
+    assert torch.equal(dw_i, dw_p)
+    # a descriptor whose kernel cannot serve two planes is refused, not silently misread
+    small = ops.conv_desc(1, 32, 32, 2 * Cs, Cs, 32, 32, Co, Co, 3, 3, 1, 1, 1, cp, src_split=(Cs, 32 * 32 * Cs))
+    assert not ops.conv_split_ok(small, 0)
+    with pytest.raises(Exception, match="two-plane"):
+        ops.conv_igemm(small, planes, wp, out_p)
