@@ -369,6 +369,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
 // written (-2 tensor passes of the largest activation).  dz is rounded to bf16 exactly as the stored form would be.
 // ws: one row [C*9] of weight-gradient partial sums per workgroup (threads combined in a fixed order through LDS);
 // red_fold_launch adds the rows in row order into dw: no float atomics.
+// STAGE: the flat pixel window of the workgroup's slice (+ one image row and one pixel either side) is copied into LDS
+// first and the 9 taps of a pixel are LDS reads masked at the image borders (as conv1_fwd_kernel).
+template <bool STAGE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned short* z, int zp, const float* gamma,
                                                                  const float* mean, const float* invstd,
                                                                  const float* red, float* dgamma, float* dbeta, int M,
@@ -379,6 +382,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
     extern __shared__ float sm[];   // [2][C] BN sums, [C*9] conv weights (z == null), [pixel lanes][C*9] thread partials
     float* swc = sm + 2 * C;
     float* spart = sm + 11 * C;
+    float* sx = spart + (size_t)(256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1) * 9 * C;     // (STAGE) the pixel window
+    if constexpr (STAGE) {
+        int pp = ppb;
+        const int w0 = (int)slice_begin(pp);
+        const int w1 = min(M, w0 + pp);
+        const int n = (w1 - w0) + 2 * W + 2;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int g = w0 - W - 1 + i;
+            sx[i] = (g >= 0 && g < M) ? x[g] : 0.f;
+        }
+    }
     if (!z)
         for (int i = threadIdx.x; i < C * 9; i += 256) swc[i] = wconv[i];
     for (int cc = threadIdx.x; cc < C; cc += 256) {
@@ -425,10 +439,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
         int yy = row % H;
         const int stepx = PL4 % W, stepr = PL4 / W;
         auto load_px = [&](u32x2& zq, u32x2& gq, f32x2 v[5]) {
-            const float* img = x + (int64_t)(row - yy) * W;
             gq = *(const u32x2*)(dy + (int64_t)m * dyp + c);
             float t[10];
-            conv1_taps(img, yy, xx, H, W, t);
+            if constexpr (STAGE) {
+                const float* p = sx + (m - m0);               // tap (ky, kx) = p[ky * W + kx]
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool ok = (ky != 0 || yy > 0) && (ky != 2 || yy < H - 1) && (kx != 0 || xx > 0) && (kx != 2 || xx < W - 1);
+                        const float tv = p[ky * W + kx];
+                        t[ky * 3 + kx] = ok ? tv : 0.f;
+                    }
+            } else {
+                conv1_taps(x + (int64_t)(row - yy) * W, yy, xx, H, W, t);
+            }
             t[9] = 0.f;
             if (z) {
                 zq = *(const u32x2*)(z + (int64_t)m * zp + c);
@@ -721,9 +746,16 @@ extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const floa
     rows_split(M, 256 / (C >> 2), &blocks, &ppb);
     const int ppb_signed = next_traversal() ? -(int)ppb : (int)ppb;
     const int PL4 = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
-    hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(2 * C + 9 * C + PL4 * 9 * C) * sizeof(float),
-                       (hipStream_t)stream, z, z_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, (int)M, C, dy,
-                       dy_pitch, scale, shift, x, H, W, ws, w, ppb_signed);
+    const size_t base_lds = (size_t)(2 * C + 9 * C + PL4 * 9 * C) * sizeof(float);
+    const size_t win = (size_t)(ppb + 2 * (int64_t)W + 2) * sizeof(float);
+    if (base_lds + win <= 60 * 1024 && !getenv("AAU_CONV1_NOSTAGE"))
+        hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel<true>, dim3((unsigned)blocks), dim3(256), base_lds + win,
+                           (hipStream_t)stream, z, z_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, (int)M, C, dy,
+                           dy_pitch, scale, shift, x, H, W, ws, w, ppb_signed);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_conv1_kernel<false>, dim3((unsigned)blocks), dim3(256), base_lds,
+                           (hipStream_t)stream, z, z_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, (int)M, C, dy,
+                           dy_pitch, scale, shift, x, H, W, ws, w, ppb_signed);
     red_fold_launch(ws, C * 9, (int)blocks, nullptr, 0, dw, C * 9, nullptr, (hipStream_t)stream);
     return check_launch("aau_bn_bwd_apply_conv1");
 }
