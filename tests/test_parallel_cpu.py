@@ -87,9 +87,12 @@ def test_bucket_plan_is_contiguous_and_ordered():
     st = ParamStore(model, torch.device("cpu"))
     numels = {n: p.numel() for n, p in zip(st.names, st.params)}
     r = A.bucket_ranges(st.names, st.offs, numels, st.total)
-    assert set(r) == {"u3", "u4", "bridge", "d1"}
+    assert set(r) == {"u3", "u4", "bridge", "d4", "d1"}
     # flat order is registration order: encoder first, decoder + out_conv last
-    assert r["d1"][0] == 0 and r["d1"][1] == r["bridge"][0] and r["bridge"][1] == r["u4"][0] and r["u4"][1] == r["u3"][0]
+    assert r["d1"][0] == 0 and r["d1"][1] == r["d4"][0] and r["d4"][1] == r["bridge"][0]
+    assert r["bridge"][1] == r["u4"][0] and r["u4"][1] == r["u3"][0]
+    # the bucket that fires last (nothing left to overlap it with) is the small one
+    assert r["d1"][1] - r["d1"][0] < 0.4 * (r["d4"][1] - r["d4"][0])
     assert r["u3"][1] == st.total
     # channels_last parameter views: logical OIHW shape, K-contiguous physical order
     w = dict(model.named_parameters())["d2.0.block.0.weight"]
