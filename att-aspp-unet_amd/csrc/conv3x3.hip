@@ -580,9 +580,8 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
 // Where the time goes (scripts/bench_c3fixed.py + the AAU_C3_ABL / AAU_C3_NOSTORE timing ablations, 8 x 256 x 256,
 // 384 -> 96 channels): the bare read + MFMA + barrier loop runs at 1741 TFLOP/s; the weight LDS-DMA costs 9 %, the
 // halo LDS-DMA 12 %, the output stores 5 %, the statistics epilogue 3-5 %: 1300 as shipped.  ~5 us per workgroup
-// (address tables, first round trip, epilogue) do not shrink with Cin; a PERSISTENT form that carried the chunk
-// stream across tile boundaries (next tile's first halo / weights in flight under the epilogue, statistics published
-// once) measured +-0 on every layer at 256 VGPRs + spills and was removed again.
+// (address tables, first round trip, epilogue) do not shrink with Cin: conv3x3p_kernel below is the persistent form
+// that hides them under the previous tile's epilogue (the default; this kernel stays as its A/B partner).
 template <int BQ>
 __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
     static_assert(BQ % 32 == 0, "two channel halves of whole 16-channel tiles");
@@ -831,6 +830,296 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_kernel(const C3Args a) {
         __syncthreads();
         stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the column-step kernel (conv3x3p; AAU_C3_NOPERSIST=1 switches back): G resident workgroups walk over tiles
+// t, t + G, ... and the chunk / column pipeline runs THROUGH the tile boundary -- the last chunk of a tile issues the
+// first halo and the first weight column of the workgroup's next tile, so that round trip and the address set-up hide
+// under the epilogue.  Statistics are published per tile through the halo buffer the finished tile no longer needs.
+template <int BQ>
+__global__ __launch_bounds__(256, 2) void conv3x3p_kernel(const C3Args a, int ntiles) {
+    static_assert(BQ % 32 == 0, "two channel halves of whole 16-channel tiles");
+    constexpr int BK = 32, HW_ = 18, HROWS = 324, NI = BQ / 32, MI = 8, QH = BQ / 2;
+    constexpr int HPIECES = 21, WPIECES = 3 * BQ / 16, WLW = (WPIECES + 3) / 4;
+    constexpr int HALO_E = HPIECES * 16 * BK, WT_E = BQ * BK, SLOT_E = 3 * WT_E;
+    constexpr int NST = NI * MI;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_p[];
+    unsigned short* smem = smem_p;
+    unsigned short* const scratch = smem + 2 * HALO_E + 2 * SLOT_E;     // 512 elements
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int rh = wave >> 1, qh = wave & 1;
+    const int ntq = (d.Cout + BQ - 1) / BQ;
+    const int G = gridDim.x;                          // multiple of ntq (host)
+    int bid = (int)blockIdx.x;
+    {
+        const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+    }
+    const int tq = bid % ntq, q0 = tq * BQ;           // the same for every tile of this workgroup
+    const bool full_q = q0 + BQ <= d.Cout;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+
+    unsigned tailmask = 0;
+    const int tail_c0 = (a.nchunk - 1) * BK;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+        if (tail_c0 + swz32(hr, lane & 3) * 8 < d.Cin) tailmask |= 1u << i;
+    }
+    const bool has_tail = d.Cpad != d.Cin;
+    unsigned hoff[6];
+    auto tile_coords = [&](int tile, int& n, int& y0, int& x0) {
+        if (a.rev) tile = ntiles - 1 - tile;
+        int patch = tile / ntq;
+        const int px_t = patch % a.tiles_x;
+        patch /= a.tiles_x;
+        const int py_t = patch % a.tiles_y;
+        n = patch / a.tiles_y; y0 = py_t * 16; x0 = px_t * 16;
+    };
+    auto set_hoff = [&](int tile) {        // tile >= ntiles: nothing to fetch (all out of range)
+        int n, y0, x0;
+        tile_coords(tile < ntiles ? tile : 0, n, y0, x0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int hr = (i * 4 + wave) * 16 + (lane >> 2);
+            const int lc = swz32(hr, lane & 3);
+            const int hy = hr / HW_, hx = hr - hy * HW_;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = tile < ntiles && hr < HROWS && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+            hoff[i] = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc * 8) * 2) : OOB;
+        }
+    };
+    unsigned woff[WLW];
+#pragma unroll
+    for (int j = 0; j < WLW; ++j) {
+        const int p = j * 4 + wave;
+        const int k = p / (BQ / 16), row = (p - k * (BQ / 16)) * 16 + (lane >> 2);
+        const int lc = swz32(row, lane & 3);
+        const bool ok = p < WPIECES && (q0 + row) < d.Cout;
+        woff[j] = ok ? (unsigned)((((q0 + row) * 9 + 3 * k) * d.Cpad + lc * 8) * 2) : OOB;
+    }
+    auto issue_halo = [&](int chunk, int buf) {
+        const bool last = has_tail && chunk == a.nchunk - 1;
+        unsigned short* base = smem + buf * HALO_E;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int p = i * 4 + wave;
+            const unsigned v = (last && !((tailmask >> i) & 1)) ? OOB : hoff[i];
+            unsigned short* dst = (p < HPIECES) ? base + p * 16 * BK : scratch;      // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dst), 16, (int)v, chunk * BK * 2, 0, 0);
+        }
+    };
+    auto issue_w = [&](int slot, int chunk, int tx, bool dead) {
+        const int soff = (tx * d.Cpad + chunk * BK) * 2;
+        unsigned short* base = smem + 2 * HALO_E + slot * SLOT_E;
+#pragma unroll
+        for (int j = 0; j < WLW; ++j) {
+            const int p = j * 4 + wave;
+            unsigned short* dst = (p < WPIECES) ? base + p * 16 * BK : scratch;      // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dst), 16, (int)(dead ? OOB : woff[j]), soff, 0, 0);
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+    int aoff[3][MI + 2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < MI + 2; ++r) {
+            const int hr = (rh * MI + r) * HW_ + fr + t;
+            aoff[t][r] = hr * BK + swz32(hr, fk) * 8;
+        }
+    const int boff = 2 * HALO_E + (qh * QH + fr) * BK + swz32(fr, fk) * 8;
+    const bool want_stats = a.stats != nullptr;
+
+    auto step = [&](const int buf, const int tx, const int slot, int chunk, int nc, const bool prev_halo, bool after_store,
+                    bool wdead) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (prev_halo) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (after_store) {            // the finished tile's stores may stay in flight; what they followed is back
+            if constexpr (NST == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned short* hb = smem + buf * HALO_E;
+        const unsigned short* wb = smem + boff + slot * SLOT_E;
+        bf16x8 af[MI + 2], wf[3][NI];
+        wf[0][0] = *(const bf16x8*)(wb);
+#pragma unroll
+        for (int r = 0; r < MI; ++r) af[r] = *(const bf16x8*)(hb + aoff[tx][r]);
+#pragma unroll
+        for (int ni = 1; ni < NI; ++ni) wf[0][ni] = *(const bf16x8*)(wb + ni * 16 * BK);
+#pragma unroll
+        for (int k = 1; k < 3; ++k) {
+            wf[k][0] = *(const bf16x8*)(wb + k * WT_E);
+            af[MI - 1 + k] = *(const bf16x8*)(hb + aoff[tx][MI - 1 + k]);
+#pragma unroll
+            for (int ni = 1; ni < NI; ++ni) wf[k][ni] = *(const bf16x8*)(wb + k * WT_E + ni * 16 * BK);
+        }
+        if (tx == 2) issue_w(slot ^ 1, nc, 0, wdead);
+        else issue_w(slot ^ 1, chunk, tx + 1, false);
+        if (tx == 0) issue_halo(nc, buf ^ 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = AAU_MFMA16(wf[k][ni], af[mi + k], acc[ni][mi], 0, 0, 0);
+        constexpr int NRD = MI + 2 + 3 * NI, NMF = 3 * NI * MI;
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < NRD - 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (tx == 0) {
+#pragma unroll
+            for (int i = 0; i < WLW + 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - (NRD - 4) - 4 * (WLW + 6), 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < WLW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - (NRD - 4) - 4 * WLW, 0);
+        }
+    };
+
+    // epilogue of one tile; `fbuf` = the halo buffer this tile's last chunk used (free now: scratch for the statistics)
+    auto epilogue = [&](int tile, int fbuf) {
+        int n, y0, x0;
+        tile_coords(tile, n, y0, x0);
+        float s1[NI][4], s2[NI][4];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int y = y0 + rh * MI + mi, x = x0 + fr;
+            const int64_t pixel = ((int64_t)n * d.H + y) * d.W + x;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int q = q0 + qh * QH + ni * 16 + 4 * fk;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+                acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (q >= d.Cout) continue;
+                if (want_stats) epi_stats(a, pixel, q, v, s1[ni], s2[ni]);
+                if (a.bias) {
+                    const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b[r];
+                }
+                if (a.scale) {
+                    const f32x4 sc = *(const f32x4*)(a.scale + q);
+                    const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+                }
+                unsigned short* out = a.dst + pixel * d.dst_pitch + q;
+                if (d.accumulate) {
+                    const u32x2 old = *(const u32x2*)out;
+                    v[0] += pair_lo(old[0]);
+                    v[1] += pair_hi(old[0]);
+                    v[2] += pair_lo(old[1]);
+                    v[3] += pair_hi(old[1]);
+                }
+                if (d.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                u32x2 pk;
+                pk[0] = pack2(v[0], v[1]);
+                pk[1] = pack2(v[2], v[3]);
+                *(u32x2*)out = pk;
+            }
+        }
+        if (want_stats) {
+            float* sst = (float*)(smem + fbuf * HALO_E);      // [4][2][BQ]
+            __syncthreads();                                  // every wave has finished reading that halo buffer
+            for (int i = tid; i < 4 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
+            __syncthreads();
+            float* mine = sst + wave * 2 * BQ + qh * QH;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                    if (fr == 0) {
+                        mine[ni * 16 + 4 * fk + r] = x1;
+                        mine[BQ + ni * 16 + 4 * fk + r] = x2;
+                    }
+                }
+            }
+            __syncthreads();
+            stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
+        }
+    };
+
+    // ---- the chunk stream of this workgroup's tiles ----
+    int tile = bid, c = 0;
+    bool after_store = false;
+    const bool count_stores = full_q && !d.accumulate && !want_stats;   // then exactly NST stores follow the last loads
+    set_hoff(tile);
+    issue_halo(0, 0);
+    issue_w(0, 0, 0, false);
+    while (true) {
+        {   // even chunk of the stream: halo buffer 0, weight slots 0 1 0
+            const bool last = c == a.nchunk - 1;
+            const int nc = last ? 0 : c + 1;
+            if (last) set_hoff(tile + G);                  // the halo issued in this chunk belongs to the next tile
+            step(0, 0, 0, c, nc, false, after_store, false);
+            after_store = false;
+            step(0, 1, 1, c, nc, true, false, false);
+            step(0, 2, 0, c, nc, false, false, last && tile + G >= ntiles);
+            ++c;
+            if (last) {
+                epilogue(tile, 0);
+                after_store = count_stores;
+                tile += G; c = 0;
+                if (tile >= ntiles) break;
+                if (a.nchunk > 1) set_hoff(tile);          // chunk 1.. of the new tile
+            }
+        }
+        {   // odd chunk of the stream: halo buffer 1, weight slots 1 0 1
+            const bool last = c == a.nchunk - 1;
+            const int nc = last ? 0 : c + 1;
+            if (last) set_hoff(tile + G);
+            step(1, 0, 1, c, nc, false, after_store, false);
+            after_store = false;
+            step(1, 1, 0, c, nc, true, false, false);
+            step(1, 2, 1, c, nc, false, false, last && tile + G >= ntiles);
+            ++c;
+            if (last) {
+                epilogue(tile, 1);
+                after_store = count_stores;
+                tile += G; c = 0;
+                if (tile >= ntiles) break;
+                if (a.nchunk > 1) set_hoff(tile);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // out-of-range pieces of the last steps still write zeros
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1861,6 +2150,19 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
             attrh = true;
         }
         const size_t ldsh = (size_t)(2 * 336 * 32 + 2 * 3 * 96 * 32 + 512) * 2;
+        if (!getenv("AAU_C3_NOPERSIST") && !getenv("AAU_C3_NOSTORE") && !getenv("AAU_C3_ABL") && grid < 0x7fffffff) {
+            const int ntq = (d->Cout + 95) / 96;
+            int G = 512 / ntq * ntq;                        // two workgroups per CU, a multiple of the channel-tile count
+            if (G > grid) G = (int)grid;
+            static bool attrp = false;
+            if (!attrp) {
+                hipFuncSetAttribute((const void*)conv3x3p_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attrp = true;
+            }
+            prof_tag("conv3x3p<96>");
+            hipLaunchKernelGGL((conv3x3p_kernel<96>), dim3((unsigned)G), dim3(256), ldsh, s, a, (int)grid);
+            return check_launch("aau_conv_igemm(3x3 halo, column steps, persistent)");
+        }
         prof_tag("conv3x3h<96>");
         if (getenv("AAU_C3_NOSTORE")) a.rev |= 2;
         if (const char* e = getenv("AAU_C3_ABL")) a.rev |= atoi(e) & 12;
