@@ -113,3 +113,92 @@ def param_groups(model, lr):
     if att:
         groups.append({"params": att, "lr": lr})
     return groups
+
+
+def build_criterion(base, edge, edge_w: float, args):
+    """test_ablation.py:346-361 (the ablation script's argument order; ``edge_w = 0`` is its ``--no_edge_loss``)."""
+    from argparse import Namespace
+    from .losses import build_criterion as _bc
+    return _bc(Namespace(stage=args.stage, neg_bce_w=args.neg_bce_w, edge_w=float(edge_w)), base, edge)
+
+
+def train(args, train_loader=None, val_loader=None):
+    """test_ablation.py:540-670: the ablation family's training loop -- model flags ``no_att`` / ``no_aspp`` /
+    ``att_depth``, attention parameters at twice the backbone's learning rate (:576-586), warm-up + cosine schedule,
+    ``--no_edge_loss``, per-epoch train / validation loss, Dice and IoU written to ``metrics.csv`` (:605-609), best
+    checkpoint by validation Dice, early stopping.  bf16 activations with fp32 master weights replace fp16 autocast +
+    GradScaler; the loaders are any iterables of ``(x, y)`` batches (synthetic phantoms with ``--synthetic_batches N``)."""
+    import csv
+    from datetime import datetime
+    from pathlib import Path
+    from .losses import ComboLoss, DiceLoss, EdgeLoss, seg_metrics
+    from .optim import FusedAdamW
+    from .pipeline import (EARLY_STOP_PATIENCE, GRAD_CLIP, IMG_SIZE, WEIGHT_DECAY, SyntheticLoader, load_state_dict_compat,
+                           lr_at_epoch, set_seed)
+    set_seed(args.seed)
+    device = torch.device("cuda", torch.cuda.current_device())
+    if train_loader is None:
+        n = int(getattr(args, "synthetic_batches", 0) or 0)
+        if n <= 0:
+            raise RuntimeError("no dataset reader on this machine (cv2/albumentations absent): pass loaders or --synthetic_batches N")
+        size = int(getattr(args, "img_size", IMG_SIZE))
+        train_loader = SyntheticLoader(n, args.batch_size, size, args.seed, device)
+        val_loader = SyntheticLoader(max(1, n // 10), args.batch_size, size, args.seed + 100000, device, neg_frac=0.0)
+    model = AttentionASPPUNet(base_c=args.base_c, use_att=not getattr(args, "no_att", False),
+                              use_aspp=not getattr(args, "no_aspp", False), att_depth=getattr(args, "att_depth", 4)).to(device)
+    if args.stage == "finetune":
+        load_state_dict_compat(model, args.pretrained)
+    opt = FusedAdamW(model, groups=param_groups(model, args.lr), weight_decay=WEIGHT_DECAY, max_grad_norm=GRAD_CLIP)
+    base_lrs = [g["lr"] for g in opt.param_groups]
+    crit = build_criterion(ComboLoss(), EdgeLoss(), 0.0 if getattr(args, "no_edge_loss", False) else args.edge_w, args)
+    out_dir = Path(args.output_dir) / ("ckpt_main" if args.stage == "main" else "ckpt_finetune")
+    out_dir.mkdir(parents=True, exist_ok=True)
+    best, noimp = 0.0, 0
+    best_p = out_dir / f"best_{datetime.now():%Y%m%d-%H%M%S}.pt"
+    history = []
+    with open(out_dir / "metrics.csv", "w", newline="") as mfp:
+        writer = csv.writer(mfp)
+        writer.writerow(["epoch", "train_loss", "val_loss", "train_dice", "val_dice", "train_iou", "val_iou"])
+        for ep in range(1, args.epochs + 1):
+            for g, lr0 in zip(opt.param_groups, base_lrs):        # SequentialLR(LinearLR, CosineAnnealingLR), per group
+                g["lr"] = lr_at_epoch(ep - 1, args.epochs, lr0, args.stage)
+            model.train()
+            acc = torch.zeros(3, device=device)
+            nb = 0
+            for x, y in train_loader:
+                x, y = x.to(device), y.to(device)
+                opt.zero_grad(set_to_none=True)
+                logits, _ = model(x)
+                loss = crit(logits, y)
+                loss.backward()
+                opt.step()
+                with torch.no_grad():
+                    acc[0] += loss.detach()
+                    acc[1:] += seg_metrics(logits.detach(), y)   # (1 - DiceLoss, iou_score), no host sync
+                nb += 1
+            model.eval()
+            vacc = torch.zeros(3, device=device)
+            nv = 0
+            with torch.no_grad():
+                for x, y in val_loader:
+                    x, y = x.to(device), y.to(device)
+                    logits, _ = model(x)
+                    vacc[0] += crit(logits, y)
+                    vacc[1:] += seg_metrics(logits, y)
+                    nv += 1
+            tr = (acc / max(1, nb)).tolist()
+            va = (vacc / max(1, nv)).tolist()
+            print(f"Dice {va[1]:.4f} | IoU {va[2]:.4f} | Loss {va[0]:.4f}")
+            writer.writerow([ep, f"{tr[0]:.6f}", f"{va[0]:.6f}", f"{tr[1]:.6f}", f"{va[1]:.6f}", f"{tr[2]:.6f}", f"{va[2]:.6f}"])
+            mfp.flush()
+            history.append((tr[0], va[0], tr[1], va[1], tr[2], va[2]))
+            if va[1] > best:
+                best, noimp = va[1], 0
+                torch.save({k: v.contiguous() for k, v in model.state_dict().items()}, best_p)
+                print(f"best saved -> {best_p}")
+            else:
+                noimp += 1
+                if noimp >= EARLY_STOP_PATIENCE:
+                    print("Early stop")
+                    break
+    return model, history

@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
             {   // prefetch the next (patch, chunk) tile into the other buffer
                 int np = patch, nc = chunk + 1;
                 if (nc == a.nchunk) { nc = 0; np += stride; }
-                if (np < npatch) issue_halo((t + 1) & 1, np, nc);
+                if (np < npatch && !(a.rev & 8)) issue_halo((t + 1) & 1, np, nc);
             }
             const unsigned short* hbase = sH(t & 1);
 #pragma unroll
@@ -1698,7 +1698,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                        if (!(a.rev & 4)) acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);   // (rev & 2/4/8: timing-only ablations, AAU_RESW_ABL)
 #ifdef AAU_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1737,7 +1737,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
                 u32x2 pk;
                 pk[0] = pack2(v[0], v[1]);
                 pk[1] = pack2(v[2], v[3]);
-                *(u32x2*)(a.dst + pixel * d.dst_pitch + q) = pk;
+                if (!(a.rev & 2)) *(u32x2*)(a.dst + pixel * d.dst_pitch + q) = pk;
             }
         }
     }
@@ -2090,6 +2090,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                     attr2 = true;
                 }
                 prof_tag("conv3x3_resw2");
+                if (const char* e = getenv("AAU_RESW_ABL")) a.rev |= atoi(e) & 14;
                 hipLaunchKernelGGL(conv3x3_resw2_kernel, dim3(gx2, 1), dim3(512), lds2, s, a, npatch);
                 return check_launch("aau_conv_igemm(3x3 resident weights, two patch streams)");
             }
