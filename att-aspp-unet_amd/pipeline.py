@@ -149,11 +149,14 @@ def calibrate(args):
 
 @torch.inference_mode()
 def predict(args):
-    """pipeline:399-523 for PNG / JPG inputs: one mask PNG per slice, computed GPU-resident (``predict_masks``).  The
-    circumference measurement (cv2.findContours / fitEllipse, :350-374) and the MHA reader / writer (SimpleITK) are host
-    contour geometry and file formats outside the hot path: masks are written, AC is not."""
+    """pipeline:399-523 for PNG / JPG inputs: one mask PNG per slice, computed GPU-resident (``predict_masks``), and --
+    when ``--spacing_json`` names the case -- its abdominal circumference (``measure.measure_ac_mm``, :359-374) collected
+    into ``ac_results.csv`` (:517-523).  ``.mha`` sweeps (SimpleITK reader / writer, :485-515) are a file format outside
+    the hot path: use ``predict_masks`` + ``measure.select_best`` on the decoded frames."""
+    import csv
     import json
     from PIL import Image
+    from . import measure
     set_seed()
     device = torch.device("cuda")
     thr = 0.48
@@ -163,6 +166,20 @@ def predict(args):
             thr = float(json.load(open(cfg))["best_thr"])
         except Exception:
             pass
+    spacing_map = {}
+    if getattr(args, "spacing_json", None):
+        try:
+            spacing_map = json.load(open(args.spacing_json, "r"))
+        except Exception as e:
+            print(f"cannot load spacing_json: {e}")
+
+    def spacing_of(case_id):                     # :420-431: {"spacing": [sx, sy]} or [sx, sy]
+        v = spacing_map.get(case_id)
+        if isinstance(v, dict) and "spacing" in v:
+            v = v["spacing"]
+        if isinstance(v, (list, tuple)) and len(v) >= 2:
+            return float(v[0]), float(v[1])
+        return None
     model = AttentionASPPUNet(base_c=args.base_c).to(device)
     model.load_state_dict(torch.load(args.weights, map_location="cpu", weights_only=True))
     # the reference predicts in fp32 (pipeline:436-437); IEEE half is 8x closer to that than bfloat16 at the same speed
@@ -170,13 +187,33 @@ def predict(args):
     model.eval().set_precision(getattr(args, "precision", "fp16"))
     od = Path(args.out_dir)
     od.mkdir(exist_ok=True, parents=True)
-    done = []
+    done, rows = [], []
     for p in sorted(Path(args.input_dir).iterdir()):
         if p.suffix.lower() not in {".png", ".jpg", ".jpeg"}:
             continue
         mask = predict_masks(model, _read_gray(p), thr)[0]
         Image.fromarray((mask * 255).cpu().numpy()).save(od / f"{p.stem}_mask.png")
         done.append(p.stem)
+        stem = p.stem                                            # :460-469: "<case>_s<frame>"
+        case_id, frame_idx = stem, -1
+        if "_s" in stem:
+            case_id = stem.split("_s")[0]
+            try:
+                frame_idx = int(stem.split("_s")[1])
+            except Exception:
+                frame_idx = -1
+        sp = spacing_of(case_id)
+        if sp is None:
+            print(f"no spacing for {case_id}, skip AC")
+        else:
+            ac_mm = round(measure.measure_ac_mm(mask, sp), 1)
+            rows.append((case_id, frame_idx, ac_mm))
+            print(f"{stem}: AC={ac_mm:.1f} mm")
+    if rows:
+        with open(od / "ac_results.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["case_id", "frame_idx", "ac_mm"])
+            w.writerows(rows)
     return done
 
 
