@@ -18,6 +18,7 @@
 // projection convs (:71-78), the gate 1x1 convs (:88-89), ConvTranspose2d(2,2) (:101,
 // as a GEMM with N = 4*Co and a pixel-shuffle store) and their input gradients.
 #include "common.h"
+#include <type_traits>
 
 namespace aau {
 
@@ -50,19 +51,30 @@ struct IgemmArgs {
 
 // SMALL = half-height pixel tile (64 x 96): for the 32x32-resolution layers (M = 8192) the regular tiling
 // yields only 256 workgroups (one per CU, 1 wave per SIMD); 512 smaller ones hide twice the latency.
+//
+// BQ = 192 is the wide tile for the long-K GEMMs of the ASPP bridge and the ConvTranspose layers: 128 pixels x 192
+// channels on 8 waves (2 x 4, the same 64 x 48 wave tile), filled THROUGH REGISTERS into two LDS buffers (80 KiB,
+// dynamic).  What bounds those layers is the rate at which a CU can fill LDS: a K-step of the 128 x 96 tile moves
+// 28.7 KB for 1.57 MFLOP (55 FLOP/B), the 128 x 192 tile 41 KB for 3.15 MFLOP (77 FLOP/B), and LDS-DMA tops out near
+// 100 GB/s per CU without overlapping the multiply (see the main loop).
 template <int BK, int BQ, bool SMALL = false>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
-    constexpr int BP = SMALL ? 64 : ((BQ == 96) ? 128 : 256);
+__global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const IgemmArgs a) {
+    constexpr int NWV = (BQ == 192) ? 8 : 4;  // waves
+    constexpr bool WIDE = (BQ == 192);        // register-staged main loop, 8 waves
+    constexpr int BP = SMALL ? 64 : ((BQ == 96 || BQ == 192) ? 128 : 256);
     static_assert(!SMALL || BQ == 96, "the small tile is a 2x2 wave layout");
+    static_assert(BQ != 192 || BK == 64, "the wide tile is built for 64-channel K-steps");
     constexpr int SLOTS = BK / 8;            // 16-B slots per LDS row
     constexpr int RPI = 64 / SLOTS;          // rows covered by one wave-wide glds
-    constexpr int NA = BP / (4 * RPI);       // activation loads per thread per K-step
-    constexpr int NW = (BQ + 4 * RPI - 1) / (4 * RPI);  // weight loads per thread (last may be partial)
+    constexpr int NA = BP / (NWV * RPI);     // activation loads per thread per K-step
+    constexpr int NW = (BQ + NWV * RPI - 1) / (NWV * RPI);  // weight loads per thread (last may be partial)
     constexpr int MI = SMALL ? 2 : 4, NI = 3; // wave tile: 64 (32) pixels x 48 channels
     constexpr int WPX = MI * 16;
     constexpr int KSUB = BK / 32;
 
-    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BQ + BP) * BK];
+    __shared__ __attribute__((aligned(16))) unsigned short ssmem[(BQ == 192) ? 8 : 2 * (BQ + BP) * BK];
+    extern __shared__ __attribute__((aligned(16))) unsigned short dsmem[];
+    unsigned short* const smem = (BQ == 192) ? dsmem : ssmem;
     auto sW = [&](int buf) -> unsigned short* { return smem + buf * ((BQ + BP) * BK); };
     auto sA = [&](int buf) -> unsigned short* { return smem + buf * ((BQ + BP) * BK) + BQ * BK; };
 
@@ -70,14 +82,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int wp = (BQ == 96) ? (wave >> 1) : wave;
-    const int wq = (BQ == 96) ? (wave & 1) : 0;
+    const int wp = (BQ == 192) ? (wave >> 2) : (BQ == 96) ? (wave >> 1) : wave;
+    const int wq = (BQ == 192) ? (wave & 3) : (BQ == 96) ? (wave & 1) : 0;
 
     // XCD-aware tile order: consecutive tile ids (same pixel tile, different channel
     // tiles / neighbouring pixel tiles) share an XCD's L2.  Bijective remap.
     const int ntq = (d.Cout + BQ - 1) / BQ;
     const int nwg = gridDim.x;
-    int bid = a.rev ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    int bid = (a.rev & 1) ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x;
     {
         const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int slot = lane % SLOTS;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (i * 4 + wave) * RPI + lane / SLOTS;
+        const int row = (i * NWV + wave) * RPI + lane / SLOTS;
         const int m = m0 + row;
         if (m < a.M) {
             const int n = m / HoWo;
@@ -118,12 +130,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // logical chunk this lane fetches for each of its rows (swizzle on the source side)
     int lcA[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) lcA[i] = swz<BK>((i * 4 + wave) * RPI + lane / SLOTS, slot);
+    for (int i = 0; i < NA; ++i) lcA[i] = swz<BK>((i * NWV + wave) * RPI + lane / SLOTS, slot);
     const int T = d.KH * d.KW;
     unsigned wbase[NW];  // byte offset of (row q, tap 0, this lane's logical chunk) in the packed weights
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-        const int row = (j * 4 + wave) * RPI + lane / SLOTS;
+        const int row = (j * NWV + wave) * RPI + lane / SLOTS;
         const int lc = swz<BK>(row, slot);
         wbase[j] = (row < BQ && q0 + row < d.Cout) ? (unsigned)(((q0 + row) * T * d.Cpad + lc * 8) * 2) : OOB;
     }
@@ -175,15 +187,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         const bool last = has_tail && chunk == a.nchunk - 1;   // uniform
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const unsigned v = (last && !tail_ok[i]) ? OOB : abase[i];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA(buf) + (i * 4 + wave) * RPI * BK), 16, (int)v,
+            const unsigned v = ((last && !tail_ok[i]) || (a.rev & 4)) ? OOB : abase[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA(buf) + (i * NWV + wave) * RPI * BK), 16, (int)v,
                                                      soffA, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            if ((j * 4 + wave) * RPI < BQ)  // wave-uniform
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(sW(buf) + (j * 4 + wave) * RPI * BK), 16,
-                                                         (int)wbase[j], soffW, 0, 0);
+            if ((j * NWV + wave) * RPI < BQ)  // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(sW(buf) + (j * NWV + wave) * RPI * BK), 16,
+                                                         (a.rev & 8) ? (int)OOB : (int)wbase[j], soffW, 0, 0);
         }
     };
 
@@ -229,6 +241,111 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     mask &= mask - 1;
     int chunk = 0;
     set_tap(tap);
+    if constexpr (WIDE) {
+        // REGISTER-staged fill: global -> VGPR (buffer_load_dwordx4) -> ds_write_b128, two LDS buffers, the loads of
+        // K-steps t+1 and t+2 in flight in two register sets.  The LDS-DMA form of this loop (three-deep ring) ran the
+        // bridge GEMMs at 58-60 us: 0.40 us per K-step to push 40 wave-wide DMA instructions (1 KiB each, ~24 clk apiece
+        // even when every address is out of range) PLUS 0.42 us to multiply -- the two did not overlap, whether the
+        // DMA instructions were issued in a burst or between the MFMAs.  Through registers the data returns on the
+        // vector-memory path and enters LDS at 128 B/clk, beside the ds_read traffic.
+        constexpr int NL = NA + NW;
+        static_assert(BQ % (NWV * RPI) == 0, "uniform load count per step");
+        const int nsteps = __builtin_popcount(tapmask) * a.nchunk;
+        u32x4 R0[NL], R1[NL];
+        auto gload = [&](u32x4 (&R)[NL]) {       // fetch the step at the cursor, then advance the cursor
+            const bool last = has_tail && chunk == a.nchunk - 1;
+            const int soffA = chunk * BK * 2, soffW = (tap * d.Cpad + chunk * BK) * 2;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const unsigned v = ((last && !tail_ok[i]) || (a.rev & 4)) ? OOB : abase[i];
+                R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)v, soffA, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+                R[NA + j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (a.rev & 8) ? (int)OOB : (int)wbase[j], soffW, 0);
+            if (++chunk == a.nchunk) {
+                chunk = 0;
+                if (mask) {
+                    tap = __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    set_tap(tap);
+                }
+            }
+        };
+        auto lwrite = [&](int buf, const u32x4 (&R)[NL]) {   // lane-linear image, as the DMA form writes it
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *(u32x4*)(sA(buf) + (i * NWV + wave) * RPI * BK + lane * 8) = R[i];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) *(u32x4*)(sW(buf) + (j * NWV + wave) * RPI * BK + lane * 8) = R[NA + j];
+        };
+        // fragments of one 32-channel sub-step: read one sub-step AHEAD of the MFMAs that use them.  Read right before
+        // use, the 56 wave-wide ds_read_b128 of a sub-step (8 waves x 7) all queue behind the same barrier and every
+        // wave idles ~220 clk for its data, twice per K-step (measured: 0.74 us per step with no memory traffic at all
+        // against 0.32 us of MFMA work).
+        struct Frag { bf16x8 w[NI], a[MI]; };
+        auto read_frags = [&](int buf, int kk, Frag& f) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = wq * 48 + ni * 16 + fr;
+                f.w[ni] = *(const bf16x8*)(sW(buf) + row * BK + swz<BK>(row, kk * 4 + fk) * 8);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wp * WPX + mi * 16 + fr;
+                f.a[mi] = *(const bf16x8*)(sA(buf) + row * BK + swz<BK>(row, kk * 4 + fk) * 8);
+            }
+        };
+        auto mma = [&](const Frag& f) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = AAU_MFMA16(f.w[ni], f.a[mi], acc[ni][mi], 0, 0, 0);
+        };
+        // Iteration t enters with F0 = fragments (t, sub-step 0), step t in LDS buffer t & 1, step t+1 in flight in
+        // Rnext:   read F1 <- (t, 1); fetch step t+2 -> Rfree; MFMA(F0); write step t+1 into buffer (t+1) & 1 (last read
+        // as (t-1, 1), complete before the barrier of iteration t-1); barrier; read F0 <- (t+1, 0); MFMA(F1).
+        // The steady state is branch-free (the compiler's vmcnt bookkeeping then waits for the OLDER register set only
+        // and leaves the younger fetch in flight); the last two steps run without a fetch.
+        Frag F0, F1;
+        auto iter = [&](int t, u32x4 (&Rnext)[NL], u32x4 (&Rfree)[NL], auto fetch, auto write) {
+            // sched_barrier: the reads must ISSUE ahead of the MFMAs they hide behind (left alone, the scheduler sinks
+            // them to just before their first use, one sub-step later)
+            read_frags(t & 1, 1, F1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (decltype(fetch)::value) gload(Rfree);
+            mma(F0);
+            if constexpr (decltype(write)::value) {
+                lwrite((t + 1) & 1, Rnext);
+                __syncthreads();
+                read_frags((t + 1) & 1, 0, F0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mma(F1);
+        };
+        using Y = std::integral_constant<bool, true>;
+        using N = std::integral_constant<bool, false>;
+        gload(R0);
+        if (nsteps > 1) gload(R1);
+        lwrite(0, R0);
+        __syncthreads();
+        read_frags(0, 0, F0);
+        int t = 0;
+        for (; t + 3 < nsteps; t += 2) {          // steps t+2 and t+3 exist
+            iter(t, R1, R0, Y{}, Y{});
+            iter(t + 1, R0, R1, Y{}, Y{});
+        }
+        // 1, 2 or 3 steps left; the register set holding step t+1 is R1
+        if (t + 2 < nsteps) {                     // three left
+            iter(t, R1, R0, Y{}, Y{});
+            iter(t + 1, R0, R1, N{}, Y{});
+            iter(t + 2, R1, R0, N{}, N{});
+        } else if (t + 1 < nsteps) {              // two left
+            iter(t, R1, R0, N{}, Y{});
+            iter(t + 1, R0, R1, N{}, N{});
+        } else {
+            iter(t, R1, R0, N{}, N{});
+        }
+    } else {
     stage(0, tap, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -254,6 +371,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         buf ^= 1;
         tap = ntap;
         chunk = nchk;
+    }
     }
 
     // ---- epilogue ----
@@ -333,9 +451,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         // then ONE global atomic per channel and workgroup
         // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
         // fixed-point add per channel and workgroup (common.h: stat_add)
-        float* sst = (float*)smem;                      // [4][2][BQ]
+        float* sst = (float*)smem;                      // [NWV][2][BQ]
         __syncthreads();                                // every wave is done reading the LDS tiles
-        for (int i = tid; i < 4 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
+        for (int i = tid; i < NWV * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
         float* mine = sst + wave * 2 * BQ;
 #pragma unroll
@@ -350,7 +468,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             }
         }
         __syncthreads();
-        stats_publish(sst, 4, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
+        stats_publish(sst, NWV, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -368,7 +486,7 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
 
 template <int BK, int BQ, bool SMALL = false>
 static int launch(const IgemmArgs& a, hipStream_t s) {
-    constexpr int BP = SMALL ? 64 : ((BQ == 96) ? 128 : 256);
+    constexpr int BP = SMALL ? 64 : ((BQ == 96 || BQ == 192) ? 128 : 256);
     const int ntq = (a.d.Cout + BQ - 1) / BQ;
     const int ntp = (a.M + BP - 1) / BP;
     const int64_t grid = (int64_t)ntq * ntp;
@@ -381,7 +499,21 @@ static int launch(const IgemmArgs& a, hipStream_t s) {
         snprintf(tag, sizeof(tag), "igemm<%d,%d,%d>%s", BK, BQ, SMALL ? 1 : 0, a.d.KH * a.d.KW > 1 ? (a.d.dil > 1 ? " dilated" : " taps") : "");
         prof_tag(tag);
     }
-    hipLaunchKernelGGL((igemm_kernel<BK, BQ, SMALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    if constexpr (BQ == 192) {
+        constexpr size_t lds = (size_t)2 * (BQ + BP) * BK * 2;
+        static bool attr = false;
+        if (!attr) {
+            // the kernel also has a few static words (tap mask): ask for what the ring needs, not for all 160 KiB
+            if (hipFuncSetAttribute((const void*)igemm_kernel<BK, BQ, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                set_error("aau_conv_igemm: cannot reserve %zu bytes of LDS", lds);
+                return AAU_E_INVALID;
+            }
+            attr = true;
+        }
+        hipLaunchKernelGGL((igemm_kernel<BK, BQ, SMALL>), dim3((unsigned)grid), dim3(512), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((igemm_kernel<BK, BQ, SMALL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    }
     return check_launch("aau_conv_igemm");
 }
 
@@ -446,6 +578,17 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
     const bool narrow = d->Cout <= 48;
     // long-K, few-tile problems (bridge at 32x32): halve the pixel tile to double the workgroup count
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((d->Cout + 95) / 96);
+    // long-K problems whose channel count fills whole 192-wide tiles and that still yield a workgroup per CU: the wide
+    // tile (L2 -> LDS fill is what bounds them, see the kernel's header).  AAU_IGEMM_WIDE=0 / 1 forces the choice.
+    {
+        const int64_t tiles192 = (int64_t)((a.M + 127) / 128) * (d->Cout / 192);
+        bool wide = bk64 && d->Cout % 192 == 0 && tiles192 >= 224 && a.nchunk * d->KH * d->KW >= 6;
+        if (const char* e = getenv("AAU_IGEMM_WIDE")) wide = bk64 && d->Cout % 192 == 0 && atoi(e) != 0;
+        if (wide) {
+            if (const char* e = getenv("AAU_IGEMM_ABL")) a.rev |= atoi(e) & 14;   // timing ablation, results are wrong
+            return launch<64, 192>(a, (hipStream_t)stream);
+        }
+    }
     if (bk64 && !narrow && tiles128 <= 384 && a.nchunk * d->KH * d->KW >= 16) return launch<64, 96, true>(a, (hipStream_t)stream);
     if (bk64) return narrow ? launch<64, 48>(a, (hipStream_t)stream) : launch<64, 96>(a, (hipStream_t)stream);
     return narrow ? launch<32, 48>(a, (hipStream_t)stream) : launch<32, 96>(a, (hipStream_t)stream);

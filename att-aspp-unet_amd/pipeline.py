@@ -97,7 +97,7 @@ def predict_masks(model, slices_u8, thr=0.48, batch=8, size=IMG_SIZE):
     Gaussian 5x5 -> threshold -> refine_mask.  Returns uint8 masks [N, H, W] on the device."""
     from . import imgproc
     if isinstance(slices_u8, np.ndarray):
-        slices_u8 = torch.from_numpy(np.ascontiguousarray(slices_u8))
+        slices_u8 = torch.from_numpy(np.array(slices_u8, copy=True))
     dev = next(model.parameters()).device
     sl = slices_u8.to(dev)
     if sl.dim() == 2:

@@ -9,7 +9,9 @@ LAYERS = [  # name, H(=W), Cin, Cout, k, dil
     ("d1.1", 512, 48, 48, 3, 1), ("d2.0", 256, 48, 96, 3, 1), ("d2.1", 256, 96, 96, 3, 1),
     ("d3.0", 128, 96, 192, 3, 1), ("d3.1", 128, 192, 192, 3, 1), ("d4.0", 64, 192, 384, 3, 1),
     ("d4.1", 64, 384, 384, 3, 1), ("br.1x1", 32, 384, 768, 1, 1), ("br.d6", 32, 384, 768, 3, 6),
-    ("br.d18", 32, 384, 768, 3, 18), ("br.proj", 32, 3840, 768, 1, 1), ("u4.c0", 64, 768, 384, 3, 1),
+    ("br.d12", 32, 384, 768, 3, 12), ("br.d18", 32, 384, 768, 3, 18), ("br.proj", 32, 3840, 768, 1, 1),
+    ("br.u4T", 32, 768, 1536, 1, 1), ("br.u3T", 64, 384, 768, 1, 1), ("br.u4g", 64, 384, 192, 1, 1),   # ConvT as GEMMs, a gate conv
+    ("u4.c0", 64, 768, 384, 3, 1),
     ("u3.c0", 128, 384, 192, 3, 1), ("u2.c0", 256, 192, 96, 3, 1), ("u1.c0", 512, 96, 48, 3, 1),
     ("u2.Wg", 256, 96, 48, 1, 1),
 ]
@@ -49,7 +51,7 @@ def timeit(fn, n=10):
 
 tot = {m: 0.0 for m in a.modes.split(",")}
 for name, H, Ci, Co, k, dil in LAYERS:
-    if a.only and a.only not in name:
+    if a.only and not any(o in name for o in a.only.split(",")):
         continue
     M = B * H * H
     gf = 2.0 * M * Ci * Co * k * k / 1e9
@@ -86,7 +88,7 @@ for name, H, Ci, Co, k, dil in LAYERS:
 # accumulating operands ----
 UPS = [("u1.up", 256, 96, 48), ("u2.up", 128, 192, 96), ("u3.up", 64, 384, 192), ("u4.up", 32, 768, 384)]
 for name, hi, gc, Co in UPS:
-    if a.only and a.only not in name:
+    if a.only and not any(o in name for o in a.only.split(",")):
         continue
     ho = 2 * hi
     Mi, Mo = B * hi * hi, B * ho * ho
@@ -119,7 +121,7 @@ for name, hi, gc, Co in UPS:
     print(line, flush=True)
 GATES = [("u2.gate", 256, 96), ("u3.gate", 128, 192), ("u4.gate", 64, 384)]
 for name, ho, Co in GATES:
-    if a.only and a.only not in name:
+    if a.only and not any(o in name for o in a.only.split(",")):
         continue
     Mo, Fi = B * ho * ho, Co // 2
     gf = 2 * 2.0 * Mo * Co * Fi / 1e9          # Wg and Wx together

@@ -454,3 +454,100 @@ def test_two_plane_operands_equal_the_interleaved_form(ops):
     assert not ops.conv_split_ok(small, 0)
     with pytest.raises(Exception, match="two-plane"):
         ops.conv_igemm(small, planes, wp, out_p)
+
+
+class launch_tags:
+    """Kernel-variant tags of the launches made inside the block (the library's own per-launch records)."""
+
+    def __enter__(self):
+        from att_aspp_unet_amd import _abi
+        self.abi = _abi
+        _abi.prof_collect_launches()
+        _abi.prof_enable(True)
+        self.tags = []
+        return self.tags
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        self.abi.prof_enable(False)
+        self.tags.extend(r["tag"] for r in self.abi.prof_collect_launches())
+        return False
+
+
+WIDE_CASES = [
+    # N, H, W, Cin, Cout, k, dil -- forced onto the 128 x 192 three-stage tile (AAU_IGEMM_WIDE=1)
+    (2, 16, 16, 64, 192, 1, 1),       # one K-step
+    (1, 8, 8, 320, 192, 1, 1),        # five chunks, M below one tile
+    (1, 12, 20, 128, 384, 3, 2),      # ragged M (240 = 128 + 112), 18 steps, two channel tiles
+    (2, 32, 32, 64, 192, 3, 18),      # tile-level tap skipping, one chunk per tap
+    (1, 20, 12, 192, 576, 1, 1),      # three channel tiles
+    # the bridge at its real shape (pipeline:67-83 at base_c 48): chosen by the dispatch rule itself
+    (8, 32, 32, 384, 768, 3, 6),
+    (8, 32, 32, 384, 768, 3, 12),
+    (8, 32, 32, 384, 768, 3, 18),
+    (8, 32, 32, 384, 768, 1, 1),
+    (8, 32, 32, 3840, 768, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_igemm_wide_tile_forward_and_stats(ops, case, monkeypatch):
+    N, H, W, Cin, Cout, k, dil = case
+    if N * H * W < 8192:
+        monkeypatch.setenv("AAU_IGEMM_WIDE", "1")
+    g = torch.Generator().manual_seed(sum(case))
+    x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
+    w = R.bf16_round(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    ref = R.conv_fwd(x, w, dil)
+    cpad = ops.cpad_of(Cin)
+    d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, k, k, 1, dil * (k // 2), dil, cpad)
+    out = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    stats = ops.stats_buffer(Cout)
+    with launch_tags() as tags:
+        ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(pack_fwd(w, cpad)), out, stats=stats)
+    assert any(t.startswith("igemm<64,192,0>") for t in tags), tags
+    assert rel_err(out.cpu(), ref) < 6e-3
+    s = ops.stats_totals(stats, Cout).float().cpu()
+    flat = ref.reshape(-1, Cout)
+    assert float((s[0] - flat.sum(0)).abs().max()) < 2e-3 * float(flat.abs().sum(0).max())
+    assert torch.allclose(s[1], (flat ** 2).sum(0), rtol=2e-3)
+
+
+def test_igemm_wide_tile_epilogues(ops, monkeypatch):
+    """bias + affine + ReLU + accumulate into a channel slice, and the ConvTranspose pixel-shuffle store, on the wide tile."""
+    monkeypatch.setenv("AAU_IGEMM_WIDE", "1")
+    N, H, W, Cin, Cout = 2, 12, 12, 96, 192
+    g = torch.Generator().manual_seed(77)
+    xw = R.bf16_round(torch.randn(N, H, W, Cin + 16, generator=g))
+    x = xw[..., 8:8 + Cin]
+    w = R.bf16_round(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5)
+    bias, scale, shift = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    prev = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    ref = torch.relu((R.conv_fwd(x, w) + bias) * scale + shift + prev)
+    cpad = ops.cpad_of(Cin)
+    wide = torch.zeros(N, H, W, Cout + 24, dtype=torch.bfloat16, device="cuda")
+    wide[..., 16:16 + Cout] = dev(prev.to(torch.bfloat16))
+    d = ops.conv_desc(N, H, W, Cin, Cin + 16, H, W, Cout, Cout + 24, Cpad=cpad, accumulate=1, relu=1)
+    ops.conv_igemm(d, dev(xw.to(torch.bfloat16))[..., 8:], dev(pack_fwd(w, cpad)), wide[..., 16:], bias=dev(bias),
+                   scale=dev(scale), shift=dev(shift))
+    torch.cuda.synchronize()
+    got = wide.cpu()
+    assert rel_err(got[..., 16:16 + Cout], ref) < 8e-3
+    assert float(got[..., :16].abs().max()) == 0 and float(got[..., 16 + Cout:].abs().max()) == 0
+    # ConvTranspose2d(2,2): N = 4*Co = 192 columns, pixel-shuffle store into the upper half of a concat buffer
+    N, H, W, Ci, Co = 2, 10, 14, 128, 48
+    x = R.bf16_round(torch.randn(N, H, W, Ci, generator=g))
+    wt = R.bf16_round(torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    ref = R.convT_fwd(x, wt, b)
+    cpad = ops.cpad_of(Ci)
+    wp = torch.zeros(4 * Co, 1, cpad)
+    wp[:, 0, :Ci] = wt.permute(2, 3, 1, 0).reshape(4 * Co, Ci)
+    d = ops.conv_desc(N, H, W, Ci, Ci, H, W, 4 * Co, 2 * Co, Cpad=cpad, shuffle2x2=1)
+    cat = torch.zeros(N, 2 * H, 2 * W, 2 * Co, dtype=torch.bfloat16, device="cuda")
+    with launch_tags() as tags:
+        ops.conv_igemm(d, dev(x.to(torch.bfloat16)), dev(wp.to(torch.bfloat16)), cat[..., Co:], bias=dev(b))
+    assert any(t.startswith("igemm<64,192,0>") for t in tags), tags
+    got = cat.cpu()
+    assert rel_err(got[..., Co:], ref) < 6e-3
+    assert float(got[..., :Co].abs().max()) == 0
