@@ -59,6 +59,9 @@ _SIGS = {
     "aau_conv_wgrad_ws_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int64)],
     "aau_conv_wgrad_group_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_wgrad_group": [C.POINTER(ConvDesc), P, P, P, I, P],
+    "aau_conv_igemm_group_ok": [C.POINTER(ConvDesc), I],
+    "aau_conv_igemm_group_ws_bytes": [C.POINTER(ConvDesc), I],
+    "aau_conv_igemm_group": [C.POINTER(ConvDesc), P, P, I, P, P, P],
     "aau_conv1_fwd": [P, P, P, P, I, I, I, I, P],
     "aau_conv1_wgrad": [P, P, P, I, I, I, I, P],
     "aau_pack_weights": [P, P, P, I, L, P],
@@ -154,6 +157,7 @@ def lib(kind: str | None = None) -> C.CDLL:
             fn.argtypes = sig
             fn.restype = C.c_int
         l.aau_bn_red_ws_bytes.restype = C.c_int64
+        l.aau_conv_igemm_group_ws_bytes.restype = C.c_int64
         l.aau_bn_red_ws_bytes.argtypes = [C.c_int]
         _libs[kind] = l
     return l

@@ -442,7 +442,7 @@ class Plan:
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
     def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, din_stats=None,
-                defer_wgrad=None, din_split=(0, 0)):
+                defer_wgrad=None, din_split=(0, 0), defer_dgrad=None):
         cv, bn, w = r["cv"], r["bn"], r["w"]
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
@@ -494,7 +494,10 @@ class Plan:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate, dst_split=din_split)
             # din_stats: [R][2][Cin] sums of the produced gradient (channel sums feed the ConvTranspose bias grad)
-            b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, din_stats)
+            if defer_dgrad is not None:
+                defer_dgrad.append((dd, dz, cv.pk_d, din, b.label))     # emitted later as one grouped launch
+            else:
+                b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, din_stats)
         return dz
 
     # ---- graph ----
@@ -763,9 +766,26 @@ class Plan:
             # the weight gradients of the projection and of the spatial branches go into ONE grouped launch
             # (aau_conv_wgrad_group) once every branch's dz exists; their data gradients run as before
             wg = [] if not eng.no_wgrad_group else None
+            # ... and the branches' data gradients, which all add into dL/dx of the bridge input, into ONE grouped
+            # launch as well (aau_conv_igemm_group): the sum stays in registers across the branches
+            dg = []
             self.cbr_bwd(rproj, dy, Cb, din=dcat5, dinp=ncat, defer_wgrad=wg)
             for i, r in enumerate(br):
-                self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0, defer_wgrad=wg)
+                self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0, defer_wgrad=wg,
+                             defer_dgrad=dg)
+            dgd = [g_[0] for g_ in dg]
+            if len(dg) >= 2 and ops.conv_igemm_group_ok(dgd):
+                b.label = "bridge(grouped)"
+                nws = ops.conv_igemm_group_ws_bytes(dgd) // 4
+                gws = self.new(nws, dtype=torch.float32) if nws else None
+                pack = ops.igemm_group_args(dgd, [g_[1] for g_ in dg], [g_[2] for g_ in dg], dp4, gws)
+                b.keep.extend([g_[k] for g_ in dg for k in (1, 2)])
+                b.keep.append(pack)
+                b.add("aau_conv_igemm_group", pack[0], pack[1], pack[2], pack[3], dp4, gws)
+            else:
+                for dd_, dz_, pk_, din_, lab in dg:
+                    b.label = lab
+                    b.add("aau_conv_igemm", dd_, dz_, pk_, din_, None, None, None, None)
             if wg:
                 descs = [w_[0] for w_ in wg]
                 b.label = "bridge(grouped)"

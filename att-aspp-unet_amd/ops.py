@@ -139,6 +139,34 @@ def conv_wgrad_group(descs, srcs, dzs, dws):
     check(fn("aau_conv_wgrad_group")(da, sa, za, wa, n, _stream()), "aau_conv_wgrad_group")
 
 
+def igemm_group_args(descs, srcs, wpks, dst, ws):
+    """ctypes argument pack of aau_conv_igemm_group (keep the returned tuple alive while the call may run)."""
+    n = len(descs)
+    da = (ConvDesc * n)(*descs)
+    sa = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    wa = (C.c_void_p * n)(*[t.data_ptr() for t in wpks])
+    return da, sa, wa, n, dst, ws
+
+
+def conv_igemm_group_ok(descs) -> bool:
+    n = len(descs)
+    return bool(fn("aau_conv_igemm_group_ok")((ConvDesc * n)(*descs), n))
+
+
+def conv_igemm_group_ws_bytes(descs) -> int:
+    n = len(descs)
+    return int(fn("aau_conv_igemm_group_ws_bytes")((ConvDesc * n)(*descs), n))
+
+
+def conv_igemm_group(descs, srcs, wpks, dst, ws=None):
+    """dst = (descs[0].accumulate ? dst : 0) + sum_i conv_i(srcs[i], wpks[i]) in one launch (see include/aau.h)."""
+    da, sa, wa, n, _, _ = igemm_group_args(descs, srcs, wpks, dst, ws)
+    need = conv_igemm_group_ws_bytes(descs)
+    if need and (ws is None or ws.numel() * ws.element_size() < need):
+        raise AauError(f"conv_igemm_group: workspace of {need} bytes required")
+    check(fn("aau_conv_igemm_group")(da, sa, wa, n, _p(dst), _p(ws), _stream()), "aau_conv_igemm_group")
+
+
 def conv1_fwd(x, w, z, stats, N, H, W, Cc):
     _check_stats(stats, Cc, "conv1_fwd")
     check(fn("aau_conv1_fwd")(_p(x), _p(w), _p(z), _p(stats), N, H, W, Cc, _stream()), "aau_conv1_fwd")

@@ -146,6 +146,20 @@ int aau_conv_wgrad_group_ok(const aau_conv_desc* descs, int n);
 int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* const* srcs,
                          const aau_bf16* const* dzs, float* const* dws, int n, void* stream);
 
+/* Grouped data gradient: dst = (descs[0].accumulate ? dst : 0) + sum_i conv_i(srcs[i], wpks[i]) -- n (2..8) stride-1      */
+/* same-size convolutions (1x1 or dilated 3x3, pad = dil * (k/2)) of DIFFERENT sources with the same N, H, W, Cin, Cout   */
+/* into ONE destination.  Built for the input gradient of the ASPP bridge (pipeline:80-83: the 1x1 and the three dilated  */
+/* branches all read x, so dL/dx is the sum of four data gradients with only Cout = 8c output channels at 1/16          */
+/* resolution).  The K dimension is the concatenation of every segment's (tap, channel) list, accumulated in registers     */
+/* and cut into contiguous ranges so that tiles x ranges fills the chip; the ranges leave fp32 slabs in `ws`              */
+/* (aau_conv_igemm_group_ws_bytes, 16-byte aligned, may be null when that returns 0) added in a fixed order:            */
+/* deterministic.  Cin % 64 == 0, Cpad == Cin, Cout % 192 == 0, dst_pitch % 8 == 0; descs[i > 0].accumulate must be 1.   */
+/* aau_conv_igemm_group_ok: in range AND too few 128 x 192 tiles for separate launches to fill the chip.                */
+int aau_conv_igemm_group_ok(const aau_conv_desc* descs, int n);
+int64_t aau_conv_igemm_group_ws_bytes(const aau_conv_desc* descs, int n);
+int aau_conv_igemm_group(const aau_conv_desc* descs, const aau_bf16* const* srcs, const aau_bf16* const* wpks, int n,
+                         aau_bf16* dst, float* ws, void* stream);
+
 /* Traversal hint (per calling thread).  alternate = 1: from now on every launch of the large  */
 /* streaming kernels (BN / pool / first and last layer / 3x3 and 1x1 convs / weight grads)    */
 /* walks its tensors in the direction OPPOSITE to the previous such launch, starting with     */

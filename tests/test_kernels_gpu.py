@@ -551,3 +551,76 @@ def test_igemm_wide_tile_epilogues(ops, monkeypatch):
     got = cat.cpu()
     assert rel_err(got[..., Co:], ref) < 6e-3
     assert float(got[..., :Co].abs().max()) == 0
+
+
+# ---- grouped data gradient (aau_conv_igemm_group, csrc/igemm_group.hip) ----
+def _dgrad_group_problem(ops, N, H, W, Cin, Cout, segs, seed, pitch_extra=0):
+    g = torch.Generator().manual_seed(seed)
+    descs, srcs, wpks, ref = [], [], [], 0
+    cpad = ops.cpad_of(Cin)
+    assert cpad == Cin
+    for i, (k, dil) in enumerate(segs):
+        xw = R.bf16_round(torch.randn(N, H, W, Cin + pitch_extra, generator=g))
+        w = R.bf16_round(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+        ref = ref + R.conv_fwd(xw[..., :Cin], w, dil)
+        descs.append(ops.conv_desc(N, H, W, Cin, Cin + pitch_extra, H, W, Cout, Cout, k, k, 1, dil * (k // 2), dil, cpad,
+                                   accumulate=1 if i > 0 else 0))
+        srcs.append(dev(xw.to(torch.bfloat16)))
+        wpks.append(dev(pack_fwd(w, cpad)))
+    return descs, srcs, wpks, ref
+
+
+@pytest.mark.parametrize("nsplit", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("case", [
+    (1, 12, 20, 64, 192, [(1, 1), (3, 2), (3, 5)]),         # ragged M (240), one chunk per tap
+    (2, 16, 16, 128, 384, [(3, 6), (1, 1), (3, 12), (3, 18)]),  # taps skipped per tile, two channel tiles
+    (1, 8, 8, 64, 192, [(1, 1), (1, 1)]),                   # two steps in all: some K-ranges are empty
+])
+def test_igemm_group_matches_the_sum_of_convolutions(ops, case, nsplit, monkeypatch):
+    monkeypatch.setenv("AAU_GROUP_NSPLIT", nsplit)
+    N, H, W, Cin, Cout, segs = case
+    descs, srcs, wpks, ref = _dgrad_group_problem(ops, N, H, W, Cin, Cout, segs, seed=N + H + Cin + len(segs), pitch_extra=8)
+    assert ops.conv_igemm_group_ok(descs)
+    nws = ops.conv_igemm_group_ws_bytes(descs) // 4
+    assert (nws == 0) == (nsplit == "1")
+    ws = torch.full((max(nws, 4),), float("nan"), device="cuda")
+    out = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.conv_igemm_group(descs, srcs, wpks, out, ws)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 6e-3
+    # accumulate into an existing gradient; twice the same bits
+    prev = R.bf16_round(torch.randn(N, H, W, Cout, generator=torch.Generator().manual_seed(3)))
+    descs[0].accumulate = 1
+    outs = []
+    for _ in range(2):
+        o = dev(prev.to(torch.bfloat16)).clone()
+        ops.conv_igemm_group(descs, srcs, wpks, o, ws)
+        torch.cuda.synchronize()
+        outs.append(o.cpu())
+    assert rel_err(outs[0], ref + prev) < 6e-3
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
+def test_igemm_group_at_the_real_bridge_shape_and_its_limits(ops):
+    """dL/dx of the ASPP bridge at base_c 48, batch 8, 512x512: 8x32x32, 768 -> 384, 1x1 + d6 + d12 + d18."""
+    N, H, W, Cin, Cout = 8, 32, 32, 768, 384
+    segs = [(1, 1), (3, 6), (3, 12), (3, 18)]
+    descs, srcs, wpks, ref = _dgrad_group_problem(ops, N, H, W, Cin, Cout, segs, seed=11)
+    assert ops.conv_igemm_group_ok(descs)
+    ws = torch.empty(ops.conv_igemm_group_ws_bytes(descs) // 4, device="cuda")
+    assert ws.numel() == 2 * N * H * W * Cout          # 128 tiles -> two K-ranges
+    out = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    with launch_tags() as tags:
+        ops.conv_igemm_group(descs, srcs, wpks, out, ws)
+    assert tags == ["igemm_group<128,192>"], tags
+    assert rel_err(out.cpu(), ref) < 6e-3
+    # out of range: one segment, a later segment that does not accumulate, mismatched shapes, missing workspace
+    assert not ops.conv_igemm_group_ok(descs[:1])
+    bad = [ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 6, 6, Cin) for _ in range(2)]
+    assert not ops.conv_igemm_group_ok(bad)
+    bad[1].accumulate = 1
+    assert ops.conv_igemm_group_ok(bad)
+    bad[1].Cout = 192
+    assert not ops.conv_igemm_group_ok(bad)
+    with pytest.raises(Exception):
+        ops.conv_igemm_group(descs, srcs, wpks, out, None)
