@@ -33,6 +33,7 @@ struct C3Args {
     int nchunk;          // Cpad / 32
     unsigned src_bytes, wpk_bytes;
     int tiles_x, tiles_y;
+    int nopair;          // experiment (AAU_RESW_NOPAIR): no two-taps-per-K-block packing of a short last chunk
 };
 
 // 16-B k-group swizzle of the 64-B LDS rows ([row][32 channels]).  ds_read_b128 is serviced in the lane groups
@@ -1390,6 +1391,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
     const int q0 = blockIdx.y * BQ;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+    // A last chunk with at most 16 real channels (Cin = 48: k-groups 2, 3 would be zero padding) is staged PAIRED: the
+    // upper half of halo row r holds the 16 channels of pixel r+1, and the upper half of the tap (ty, 0) weight tile the
+    // 16 channels of tap (ty, 1).  One MFMA then multiplies taps (ty, 0) and (ty, 1) together and the tap loop skips
+    // tx = 1: 9 -> 6 K-blocks for that chunk (18 -> 15 per patch at Cin = 48) with unchanged LDS read addresses -- the
+    // pairing lives entirely in the per-lane SOURCE addresses of the fills.  (Pairing arbitrary taps in the read
+    // addresses instead saves one more block but costs ~35 per-lane address registers: 256 VGPRs + scratch, slower.)
+    const bool pair_last = (d.Cin & 31) != 0 && (d.Cin & 31) <= 16 && !a.nopair;
 
     // ---- weights: all (chunk, tap) tiles of this channel tile, once ----
     {
@@ -1401,13 +1409,15 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
             const int row = r >> 2, lc = swz32(row, r & 3);
             const int chunk = tile / 9, tap = tile - chunk * 9;
             const bool ok = tile < ntile && q0 + row < d.Cout;
-            const unsigned v = ok ? (unsigned)((((q0 + row) * 9 + tap) * d.Cpad + chunk * BK + lc * 8) * 2) : OOB;
+            // paired last chunk (see pair_last): k-groups 2, 3 of the tap (ty, 0) tile hold tap (ty, 1)'s 16 channels
+            const bool pr = pair_last && chunk == a.nchunk - 1 && tap % 3 == 0 && lc >= 2;
+            const unsigned v = ok ? (unsigned)((((q0 + row) * 9 + tap + (pr ? 1 : 0)) * d.Cpad + chunk * BK + (pr ? lc - 2 : lc) * 8) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dsm + 2 * HALO_E + (base + wave * 64) * 8), 16, (int)v, 0, 0, 0);
         }
     }
     // ---- halo roles (patch independent part) ----
     int hy_[HL], hx_[HL], lc_[HL];
-    bool htail[HL];
+    bool htail[HL], htail_p[HL];
     const int tail_c0 = (a.nchunk - 1) * BK;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
@@ -1416,6 +1426,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
         hy_[i] = hr < HROWS ? hr / HW_ : -100000;
         hx_[i] = hr % HW_;
         htail[i] = tail_c0 + lc_[i] * 8 < d.Cin;
+        htail_p[i] = tail_c0 + (lc_[i] - 2) * 8 < d.Cin;      // paired last chunk, upper k-groups
     }
     const bool has_tail = d.Cpad != d.Cin;
     const int split_c = d.src_split_c > 0 ? d.src_split_c : 0x7fffffff;
@@ -1435,11 +1446,15 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
         const bool last = has_tail && chunk == a.nchunk - 1;
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
-            const int y = y0 - 1 + hy_[i], x = x0 - 1 + hx_[i];
-            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
+            // paired last chunk: the upper k-groups fetch the NEXT pixel's first 16 channels of the chunk
+            const bool pr = pair_last && chunk == a.nchunk - 1 && lc_[i] >= 2;
+            const int lcs = pr ? lc_[i] - 2 : lc_[i];
+            const int y = y0 - 1 + hy_[i], x = x0 - 1 + hx_[i] + (pr ? 1 : 0);
+            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !(pr ? htail_p[i] : htail[i])) &&
+                            !(pr && hx_[i] + 1 >= HW_);
             // two-plane source (aau.h): this lane's 8 channels of the chunk may live in the second plane
-            const int sadj = (chunk * BK + lc_[i] * 8 >= split_c) ? split_adj : 0;
-            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8 + sadj) * 2) : OOB;
+            const int sadj = (chunk * BK + lcs * 8 >= split_c) ? split_adj : 0;
+            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lcs * 8 + sadj) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * NW + wave) * 16 * BK), 16, (int)v,
                                                      chunk * BK * 2, 0, 0);
         }
@@ -1480,9 +1495,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
                 if (np < npatch) issue_halo((t + 1) & 1, np, nc);
             }
             const unsigned short* hbase = sH(t & 1);
+            const bool paired = pair_last && chunk == a.nchunk - 1;     // wave-uniform
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ty = tap / 3, tx = tap % 3;
+                if (tx == 1 && paired) continue;                        // multiplied together with tap (ty, 0)
                 const unsigned short* wbase = sWt(chunk, tap);
                 bf16x8 wf[NI], af[MI];
 #pragma unroll
@@ -1593,6 +1610,13 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
     const int q0 = blockIdx.y * BQ;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+    // A last chunk with at most 16 real channels (Cin = 48: k-groups 2, 3 would be zero padding) is staged PAIRED: the
+    // upper half of halo row r holds the 16 channels of pixel r+1, and the upper half of the tap (ty, 0) weight tile the
+    // 16 channels of tap (ty, 1).  One MFMA then multiplies taps (ty, 0) and (ty, 1) together and the tap loop skips
+    // tx = 1: 9 -> 6 K-blocks for that chunk (18 -> 15 per patch at Cin = 48) with unchanged LDS read addresses -- the
+    // pairing lives entirely in the per-lane SOURCE addresses of the fills.  (Pairing arbitrary taps in the read
+    // addresses instead saves one more block but costs ~35 per-lane address registers: 256 VGPRs + scratch, slower.)
+    const bool pair_last = (d.Cin & 31) != 0 && (d.Cin & 31) <= 16 && !a.nopair;
 
     // ---- weights: all (chunk, tap) tiles of this channel tile, once ----
     {
@@ -1604,13 +1628,15 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
             const int row = r >> 2, lc = swz32(row, r & 3);
             const int chunk = tile / 9, tap = tile - chunk * 9;
             const bool ok = tile < ntile && q0 + row < d.Cout;
-            const unsigned v = ok ? (unsigned)((((q0 + row) * 9 + tap) * d.Cpad + chunk * BK + lc * 8) * 2) : OOB;
+            // paired last chunk (see pair_last): k-groups 2, 3 of the tap (ty, 0) tile hold tap (ty, 1)'s 16 channels
+            const bool pr = pair_last && chunk == a.nchunk - 1 && tap % 3 == 0 && lc >= 2;
+            const unsigned v = ok ? (unsigned)((((q0 + row) * 9 + tap + (pr ? 1 : 0)) * d.Cpad + chunk * BK + (pr ? lc - 2 : lc) * 8) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dsm + 4 * HALO_E + (base + wave8 * 64) * 8), 16, (int)v, 0, 0, 0);
         }
     }
     // ---- halo roles (patch independent part) ----
     int hy_[HL], hx_[HL], lc_[HL];
-    bool htail[HL];
+    bool htail[HL], htail_p[HL];
     const int tail_c0 = (a.nchunk - 1) * BK;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
@@ -1619,6 +1645,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
         hy_[i] = hr < HROWS ? hr / HW_ : -100000;
         hx_[i] = hr % HW_;
         htail[i] = tail_c0 + lc_[i] * 8 < d.Cin;
+        htail_p[i] = tail_c0 + (lc_[i] - 2) * 8 < d.Cin;      // paired last chunk, upper k-groups
     }
     const bool has_tail = d.Cpad != d.Cin;
     auto patch_origin = [&](int patch, int& n, int& y0, int& x0) {
@@ -1634,9 +1661,13 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
         const bool last = has_tail && chunk == a.nchunk - 1;
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
-            const int y = y0 - 1 + hy_[i], x = x0 - 1 + hx_[i];
-            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
-            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;
+            // paired last chunk: the upper k-groups fetch the NEXT pixel's first 16 channels of the chunk
+            const bool pr = pair_last && chunk == a.nchunk - 1 && lc_[i] >= 2;
+            const int lcs = pr ? lc_[i] - 2 : lc_[i];
+            const int y = y0 - 1 + hy_[i], x = x0 - 1 + hx_[i] + (pr ? 1 : 0);
+            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !(pr ? htail_p[i] : htail[i])) &&
+                            !(pr && hx_[i] + 1 >= HW_);
+            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lcs * 8) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * 4 + wave) * 16 * BK), 16, (int)v,
                                                      chunk * BK * 2, 0, 0);
         }
@@ -1676,9 +1707,12 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
                 if (np < npatch && !(a.rev & 8)) issue_halo((t + 1) & 1, np, nc);
             }
             const unsigned short* hbase = sH(t & 1);
+            const bool paired = pair_last && chunk == a.nchunk - 1;     // wave-uniform
+#ifdef AAU_RESW2_TAPLOOP    // ablation build (scripts/gpu_resw2_ab.sh): one tap at a time, 63 reads per chunk
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ty = tap / 3, tx = tap % 3;
+                if (tx == 1 && paired) continue;
                 const unsigned short* wbase = sWt(chunk, tap);
                 bf16x8 wf[NI], af[MI];
 #pragma unroll
@@ -1691,19 +1725,44 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
                     const int hr = (wave * MI + mi + ty) * HW_ + fr + tx;
                     af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
                 }
-#ifdef AAU_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        if (!(a.rev & 4)) acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);   // (rev & 2/4/8: timing-only ablations, AAU_RESW_ABL)
-#ifdef AAU_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
+                        if (!(a.rev & 4)) acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
         }
+#else
+            // Column step with vertical reuse: for one horizontal tap offset tx the wave's MI output rows and the three
+            // vertical taps touch MI + 2 halo rows; read those once and let each feed up to three MFMA rows.  45 wave-wide
+            // ds_read_b128 per chunk (3 x (6 activation + 9 weight)) instead of 63 (9 taps x (4 + 3)).
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                if (tx == 1 && paired) continue;                        // multiplied together with the tx = 0 column
+                bf16x8 ar[MI + 2];
+#pragma unroll
+                for (int r = 0; r < MI + 2; ++r) {
+                    const int hr = (wave * MI + r) * HW_ + fr + tx;
+                    ar[r] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
+                }
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
+                    const unsigned short* wbase = sWt(chunk, ty * 3 + tx);
+                    bf16x8 wf[NI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int row = ni * 16 + fr;
+                        wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            if (!(a.rev & 4)) acc[ni][mi] = AAU_MFMA16(wf[ni], ar[mi + ty], acc[ni][mi], 0, 0, 0);   // (rev & 2/4/8: timing-only ablations, AAU_RESW_ABL)
+                }
+            }
+        }
+#endif
         // ---- per-patch epilogue ----
         int n, y0, x0;
         patch_origin(patch, n, y0, x0);
@@ -2015,6 +2074,7 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     a.wpk_bytes = wpk_bytes;
     a.tiles_x = d->W / 16;
     a.tiles_y = d->H / 16;
+    a.nopair = getenv("AAU_RESW_NOPAIR") != nullptr;
     const int BQ = d->Cout <= 48 ? 48 : 96;      // a 192-channel tile (activations read once) measured no faster
     const int ntq = (d->Cout + BQ - 1) / BQ;
     const int npatch = a.tiles_x * a.tiles_y * d->N;
@@ -2068,6 +2128,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     a.wpk_bytes = wpk_bytes;
     a.tiles_x = d->W / 16;
     a.tiles_y = d->H / 16;
+    a.nopair = getenv("AAU_RESW_NOPAIR") != nullptr;
     const bool narrow = d->Cout <= 48;
     const int BQ = narrow ? 48 : 96;
     // resident-weight persistent variant: small weight matrix, many patches, no read-modify-write epilogue
