@@ -158,6 +158,21 @@ __device__ __forceinline__ double stat_total(const long long* base, int C, int w
     return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 4503599627370496.0);
 }
 
+// Epilogue store widening for the 16x16 MFMA accumulator layout (lane = 16 * fk + fr holds channels [4 fk, 4 fk + 4) of
+// pixel fr: an 8-byte store per lane, sixteen 32-byte pieces per wave instruction).  Given the quads of TWO pixels A and
+// B of the same 16-channel group, v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of
+// the other (probe: scripts/probes/permlane16.hip), after which a lane with even fk owns channels [8 (fk >> 1), +8) of
+// pixel A and a lane with odd fk the same channels of pixel B: ONE 16-byte store (or read-modify-write) per lane for the
+// pair.  Same bytes, same addresses, half the vector-memory instructions (guide T21: such tails are issue-bound).
+__device__ __forceinline__ void swap_pair8(const float a[4], const float b[4], float out[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+        out[r] = __uint_as_float(t[0]);
+        out[4 + r] = __uint_as_float(t[1]);
+    }
+}
+
 // Workgroup part of a conv epilogue's statistics: every wave has stored its per-channel row sums in ITS OWN block of
 // `sst` ([nwaves][2][BQ] floats, zero where a wave has no share); thread t < 2*BQ adds the blocks in wave order (a fixed
 // order, unlike LDS atomics) and publishes one fixed-point add per channel and workgroup.

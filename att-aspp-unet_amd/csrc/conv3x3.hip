@@ -33,6 +33,7 @@ struct C3Args {
     int nchunk;          // Cpad / 32
     unsigned src_bytes, wpk_bytes;
     int tiles_x, tiles_y;
+    int nowide;          // experiment (AAU_NO_WIDE_STORE): 8-byte epilogue stores
     int nopair;          // experiment (AAU_RESW_NOPAIR): no two-taps-per-K-block packing of a short last chunk
 };
 
@@ -49,6 +50,46 @@ __device__ __forceinline__ int swz32(int row, int lc) { return lc ^ ((row >> 1) 
 __device__ __forceinline__ void epi_stats(const C3Args&, int64_t, int, const float v[4], float s1[4], float s2[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+}
+
+// Wide epilogue of one pair of accumulator quads (the same 16-channel group of two pixels A, B): statistics, bias and the
+// folded-BN affine in the MFMA layout (channels q .. q+3), then the cross-lane swap of common.h (swap_pair8), after which
+// this lane owns channels qw .. qw+7 of ONE of the two pixels and finishes with a single 16-byte (read-modify-)write at
+// `out`, its own destination for (that pixel, qw).  Every lane of the wave must call this (the swap is a wave operation).
+__device__ __forceinline__ void epi_pair_wide(const C3Args& a, const aau_conv_desc& d, int q, int qw, const f32x4& accA,
+                                              const f32x4& accB, bool want_stats, float s1[4], float s2[4],
+                                              unsigned short* out, bool store) {
+    float va[4], vb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { va[r] = accA[r]; vb[r] = accB[r]; }
+    if (q < d.Cout) {
+        if (want_stats) { epi_stats(a, 0, q, va, s1, s2); epi_stats(a, 0, q, vb, s1, s2); }
+        if (a.bias) {
+            const f32x4 b = *(const f32x4*)(a.bias + q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
+        }
+        if (a.scale) {
+            const f32x4 sc = *(const f32x4*)(a.scale + q);
+            const f32x4 sh = *(const f32x4*)(a.shift + q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
+        }
+    }
+    float w[8];
+    swap_pair8(va, vb, w);
+    if (qw >= d.Cout || !store) return;
+    if (d.accumulate) {
+        float o[8];
+        unpack8(*(const u32x4*)out, o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] += o[r];
+    }
+    if (d.relu) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
+    }
+    *(u32x4*)out = pack8(w);
 }
 
 // s_waitcnt takes an immediate; the pipeline below only ever needs these four counts per tile shape
@@ -944,6 +985,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3p_kernel(const C3Args a, int nt
         }
     const int boff = 2 * HALO_E + (qh * QH + fr) * BK + swz32(fr, fk) * 8;
     const bool want_stats = a.stats != nullptr;
+    // (16-byte epilogue stores through epi_pair_wide were tried here: -3 % ... +4 % per layer, no net gain -- this kernel
+    // is at its register limit and the second epilogue form spills; its store tail is ~5 % of a launch)
 
     auto step = [&](const int buf, const int tx, const int slot, int chunk, int nc, const bool prev_halo, bool after_store,
                     bool wdead) __attribute__((always_inline)) {
@@ -1469,6 +1512,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
 
     const int first = blockIdx.x, stride = gridDim.x;
     const bool full_tiles = q0 + BQ <= d.Cout;   // every lane issues all NI*MI stores of a patch
+    // 16-byte epilogue stores (epi_pair_wide) when the destination allows them
+    const bool wide = ((uintptr_t)a.dst & 15) == 0 && d.dst_pitch % 8 == 0 && !a.nowide &&
+                      (d.dst_split_c <= 0 || (d.dst_split_c % 8 == 0 && d.dst_split_off % 8 == 0));
     int t = 0;
     if (first < npatch) issue_halo(0, first, 0);
     for (int patch = first; patch < npatch; patch += stride) {
@@ -1481,7 +1527,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
             // halo(t) (and, the first time, the weights) must have landed.  At the first chunk of a later
             // patch the only younger operations are the previous patch's NI*MI output stores per lane
             // (vmcnt retires in issue order), which may stay in flight.
-            if (t > 0 && chunk == 0 && full_tiles) {
+            if (t > 0 && chunk == 0 && full_tiles && wide) {          // half as many (16-byte) stores per lane
+                if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else if (t > 0 && chunk == 0 && full_tiles) {
                 if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -1528,6 +1578,21 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_resw_kernel(const C3Args a, i
         // ---- per-patch epilogue ----
         int n, y0, x0;
         patch_origin(patch, n, y0, x0);
+        if (wide) {
+            static_assert(MI % 2 == 0, "pixel rows are stored in pairs");
+#pragma unroll
+            for (int mp = 0; mp < MI; mp += 2) {
+                const int yl = y0 + wave * MI + mp + (fk & 1);        // the row this lane stores after the swap
+                const int64_t pl = ((int64_t)n * d.H + yl) * d.W + x0 + fr;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int qw = q0 + ni * 16 + 8 * (fk >> 1);
+                    epi_pair_wide(a, d, q0 + ni * 16 + 4 * fk, qw, acc[ni][mp], acc[ni][mp + 1], want_stats, s1[ni], s2[ni],
+                                  a.dst + pl * d.dst_pitch + qw + (qw >= dsplit_c ? dsplit_adj : 0), true);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int y = y0 + wave * MI + mi, x = x0 + fr;
@@ -1682,6 +1747,8 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
 
     const int first = blockIdx.x * 2 + grp, stride = gridDim.x * 2;
     const bool full_tiles = q0 + BQ <= d.Cout;   // every lane issues all NI*MI stores of a patch
+    // 16-byte epilogue stores (epi_pair_wide) when the destination allows them
+    const bool wide = ((uintptr_t)a.dst & 15) == 0 && d.dst_pitch % 8 == 0 && !a.nowide;
     int t = 0;
     if (first < npatch) issue_halo(0, first, 0);
     for (int patch = first; patch < npatch; patch += stride) {
@@ -1694,7 +1761,10 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
             // halo(t) (and, the first time, the weights) must have landed.  At the first chunk of a later
             // patch the only younger operations are the previous patch's NI*MI output stores per lane
             // (vmcnt retires in issue order), which may stay in flight.
-            if (t > 0 && chunk == 0 && full_tiles) {
+            if (t > 0 && chunk == 0 && full_tiles && wide) {          // half as many (16-byte) stores per lane
+                if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else if (t > 0 && chunk == 0 && full_tiles) {
                 if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             } else {
@@ -1766,6 +1836,20 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
         // ---- per-patch epilogue ----
         int n, y0, x0;
         patch_origin(patch, n, y0, x0);
+        if (wide) {
+#pragma unroll
+            for (int mp = 0; mp < MI; mp += 2) {
+                const int yl = y0 + wave * MI + mp + (fk & 1);        // the row this lane stores after the swap
+                const int64_t pl = ((int64_t)n * d.H + yl) * d.W + x0 + fr;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int qw = q0 + ni * 16 + 8 * (fk >> 1);
+                    epi_pair_wide(a, d, q0 + ni * 16 + 4 * fk, qw, acc[ni][mp], acc[ni][mp + 1], want_stats, s1[ni], s2[ni],
+                                  a.dst + pl * d.dst_pitch + qw, !(a.rev & 2));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int y = y0 + wave * MI + mi, x = x0 + fr;
@@ -1909,6 +1993,8 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
 
     const int first = blockIdx.x, stride = gridDim.x;
     const bool full_tiles = q0 + BQ <= d.Cout;   // every lane issues all NI*MI stores of a patch
+    // 16-byte epilogue stores (common.h: swap_pair8) when the destination allows them
+    const bool wide = ((uintptr_t)a.dst & 15) == 0 && d.dst_pitch % 8 == 0 && (!d.shuffle2x2 || (d.Cout >> 2) % 8 == 0) && !a.nowide;
     int t = 0;
     if (first < npatch) issue_halo(0, first, 0);
     for (int patch = first; patch < npatch; patch += stride) {
@@ -1921,7 +2007,11 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             // halo(t) (and, the first time, the weights) must have landed.  At the first chunk of a later
             // patch the only younger operations are the previous patch's NI*MI output stores per lane
             // (vmcnt retires in issue order), which may stay in flight.
-            if (t > 0 && chunk == 0 && full_tiles) {
+            if (t > 0 && chunk == 0 && full_tiles && wide) {          // half as many (16-byte) stores per lane
+                if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else if (t > 0 && chunk == 0 && full_tiles) {
                 if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -1965,6 +2055,63 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
         // ---- per-patch epilogue ----
         int n, y0, x0;
         patch_origin(patch, n, y0, x0);
+        if (wide) {
+            static_assert(MI % 2 == 0, "pixel rows are stored in pairs");
+            const int Co = d.Cout >> 2;
+#pragma unroll
+            for (int mp = 0; mp < MI; mp += 2) {
+                const int yA = y0 + wave * MI + mp, x = x0 + fr;
+                const int yl = yA + (fk & 1);                         // the row this lane stores after the swap
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int q = q0 + ni * 16 + 4 * fk;
+                    float va[4], vb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { va[r] = acc[ni][mp][r]; vb[r] = acc[ni][mp + 1][r]; }
+                    if (q < d.Cout) {
+                        if constexpr (STATS) {
+                            if (want_stats) { epi_stats(a, 0, q, va, s1[ni], s2[ni]); epi_stats(a, 0, q, vb, s1[ni], s2[ni]); }
+                        }
+                        const int qv = d.shuffle2x2 ? q % Co : q;
+                        if (a.bias) {
+                            const f32x4 b = *(const f32x4*)(a.bias + qv);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
+                        }
+                        if (a.scale) {
+                            const f32x4 sc = *(const f32x4*)(a.scale + qv);
+                            const f32x4 sh = *(const f32x4*)(a.shift + qv);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
+                        }
+                    }
+                    float w[8];
+                    swap_pair8(va, vb, w);                            // every lane takes part
+                    const int qw = q0 + ni * 16 + 8 * (fk >> 1);
+                    if (qw >= d.Cout) continue;
+                    unsigned short* out;
+                    if (d.shuffle2x2) {
+                        const int pos = qw / Co;
+                        const int64_t op = ((int64_t)n * (2 * d.H) + (2 * yl + (pos >> 1))) * (2 * d.W) + (2 * x + (pos & 1));
+                        out = a.dst + op * d.dst_pitch + (qw - pos * Co);
+                    } else {
+                        out = a.dst + (((int64_t)n * d.H + yl) * d.W + x) * d.dst_pitch + qw;
+                    }
+                    if (d.accumulate) {
+                        float o[8];
+                        unpack8(*(const u32x4*)out, o);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) w[r] += o[r];
+                    }
+                    if (d.relu) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
+                    }
+                    *(u32x4*)out = pack8(w);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int y = y0 + wave * MI + mi, x = x0 + fr;
@@ -2073,6 +2220,7 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     a.src_bytes = src_bytes;
     a.wpk_bytes = wpk_bytes;
     a.tiles_x = d->W / 16;
+    a.nowide = getenv("AAU_NO_WIDE_STORE") != nullptr;
     a.tiles_y = d->H / 16;
     a.nopair = getenv("AAU_RESW_NOPAIR") != nullptr;
     const int BQ = d->Cout <= 48 ? 48 : 96;      // a 192-channel tile (activations read once) measured no faster
@@ -2127,6 +2275,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     a.src_bytes = src_bytes;
     a.wpk_bytes = wpk_bytes;
     a.tiles_x = d->W / 16;
+    a.nowide = getenv("AAU_NO_WIDE_STORE") != nullptr;
     a.tiles_y = d->H / 16;
     a.nopair = getenv("AAU_RESW_NOPAIR") != nullptr;
     const bool narrow = d->Cout <= 48;

@@ -383,6 +383,73 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
 #pragma unroll
         for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
 
+    // 16-byte epilogue stores (common.h: swap_pair8) when the destination allows them: the quads of pixel rows mi, mi+1
+    // are exchanged across k-groups so that a lane owns 8 consecutive channels of one pixel
+    const bool wide = ((uintptr_t)a.dst & 15) == 0 && d.dst_pitch % 8 == 0 && (!d.shuffle2x2 || (d.Cout >> 2) % 8 == 0) &&
+                      !(a.rev & 16);
+    if (wide) {
+        static_assert(MI % 2 == 0, "pixel rows are stored in pairs");
+        const int Co = d.Cout >> 2;
+#pragma unroll
+        for (int mp = 0; mp < MI; mp += 2) {
+            const int ml = m0 + wp * WPX + (mp + (fk & 1)) * 16 + fr;      // the pixel this lane stores after the swap
+            int n = 0, yo = 0, xo = 0;
+            if (d.shuffle2x2 && ml < a.M) {
+                n = ml / HoWo;
+                const int rem = ml - n * HoWo;
+                yo = rem / d.Wo;
+                xo = rem - yo * d.Wo;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int q = q0 + wq * 48 + ni * 16 + 4 * fk;
+                float va[4], vb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { va[r] = acc[ni][mp][r]; vb[r] = acc[ni][mp + 1][r]; }
+                if (q < d.Cout) {
+                    if (want_stats) {      // rows past M hold zeros (their loads were out of range)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { s1[ni][r] += va[r] + vb[r]; s2[ni][r] += va[r] * va[r] + vb[r] * vb[r]; }
+                    }
+                    const int qv = d.shuffle2x2 ? q % Co : q;
+                    if (a.bias) {
+                        const f32x4 b = *(const f32x4*)(a.bias + qv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
+                    }
+                    if (a.scale) {
+                        const f32x4 sc = *(const f32x4*)(a.scale + qv);
+                        const f32x4 sh = *(const f32x4*)(a.shift + qv);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
+                    }
+                }
+                float w[8];
+                swap_pair8(va, vb, w);                                     // every lane takes part
+                const int qw = q0 + wq * 48 + ni * 16 + 8 * (fk >> 1);
+                if (qw >= d.Cout || ml >= a.M) continue;
+                unsigned short* out;
+                if (d.shuffle2x2) {
+                    const int pos = qw / Co;
+                    const int64_t op = ((int64_t)n * (2 * d.Ho) + (2 * yo + (pos >> 1))) * (2 * d.Wo) + (2 * xo + (pos & 1));
+                    out = a.dst + op * d.dst_pitch + (qw - pos * Co);
+                } else {
+                    out = a.dst + (int64_t)ml * d.dst_pitch + qw;
+                }
+                if (d.accumulate) {
+                    float o[8];
+                    unpack8(*(const u32x4*)out, o);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) w[r] += o[r];
+                }
+                if (d.relu) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
+                }
+                *(u32x4*)out = pack8(w);
+            }
+        }
+    } else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m0 + wp * WPX + mi * 16 + fr;
@@ -575,6 +642,7 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
     if (conv1x1_resw_applicable(d, stats != nullptr))
         return conv1x1_resw_launch(d, src, wpk, dst, bias, scale, shift, stats, a.src_bytes, a.wpk_bytes, (hipStream_t)stream);
     a.rev = next_traversal();
+    if (getenv("AAU_NO_WIDE_STORE")) a.rev |= 16;     // experiment: 8-byte epilogue stores
     const bool narrow = d->Cout <= 48;
     // long-K, few-tile problems (bridge at 32x32): halve the pixel tile to double the workgroup count
     const int64_t tiles128 = (int64_t)((a.M + 127) / 128) * ((d->Cout + 95) / 96);
