@@ -72,6 +72,7 @@ _SIGS = {
     "aau_maxpool2": [P, I, P, I, I, I, I, I, P],
     "aau_bn_bwd_reduce": [P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, I, I, I, F, P, P, P],
     "aau_bn_bwd_apply": [P, I, P, I, P, P, P, P, P, P, L, I, P, I, P, P, I, F, P, P],
+    "aau_bn_bwd_apply_pool": [P, I, P, I, P, P, P, P, P, P, I, I, I, I, P, I, P, I, P, P, I, P],
     "aau_bn_bwd_apply_conv1": [P, I, P, P, P, P, P, P, I, I, I, I, P, I, P, P, P, P, P, P, P],
     "aau_conv1_bn_act": [P, P, P, I, P, P, I, I, I, I, P],
     "aau_conv1_bn_bwd_reduce": [P, P, P, I, P, P, P, P, P, I, I, I, I, P, P],

@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                         g[k][j] = gv;
                     }
                 }
+                if (dz)   // dz == null: aau_bn_bwd_apply_pool redoes the routing from dy, z and dpool
 #pragma unroll
-                for (int k = 0; k < 4; ++k) st16(dz + pix[k] * dzp + c, pack8(g[k]));
+                    for (int k = 0; k < 4; ++k) st16(dz + pix[k] * dzp + c, pack8(g[k]));
             } else {
                 float zz[8], g[8];
                 unpack8(ld16(z + it * zp + c), zz);
@@ -361,6 +362,88 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
             g[j] = k0[j] * (g[j] - k1[j] - zh * k2[j]);
         }
         st16(dz + m * dzp + c, pack8(g));
+    }
+}
+
+// The apply pass of a POOLED layer (the encoder's second ConvBNReLU: its output feeds the skip connection and, through
+// MaxPool2d, the next level): one thread per 2x2 window and channel group redoes what the reduce pass did -- the gradient
+// of a window is dy (skip path) plus dpool routed to the FIRST maximum of bf16(relu(bn(z))) in window order, masked by the
+// ReLU -- and applies the BatchNorm backward formula.  The reduce pass then need not store the routed gradient: one write
+// and one read of the layer's largest tensor against a re-read of dpool (a quarter of its size).
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(
+    const unsigned short* z, int zp, unsigned short* dz, int dzp, const float* gamma, const float* mean, const float* invstd,
+    const float* red, float* dgamma, float* dbeta, int N, int H, int W, int C, const unsigned short* dy, int dyp,
+    const unsigned short* dpool, int dpp, const float* scale, const float* shift, int relu, int64_t items_per_block) {
+    extern __shared__ float sm[];   // [2][C] totals of the reduce pass
+    for (int cc = threadIdx.x; cc < C; cc += 256) {
+        const float a = red[cc], b = red[C + cc];
+        sm[cc] = a;
+        sm[C + cc] = b;
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[cc] += a;
+            if (dgamma) dgamma[cc] += b;
+        }
+    }
+    __syncthreads();
+    const CGMap mp(C);
+    const int tid = threadIdx.x;
+    if (tid >= mp.T) return;
+    const int cg = tid % mp.CG, pl = tid / mp.CG, c = cg * 8;
+    float k0[8], k1[8], k2[8], mu[8], is[8], sc[8], sh[8];
+    ldf8(mean + c, mu);
+    ldf8(invstd + c, is);
+    ldf8(scale + c, sc);
+    ldf8(shift + c, sh);
+    const float Mf = (float)((int64_t)N * H * W);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        k0[j] = gamma[c + j] * is[j];
+        k1[j] = sm[c + j] / Mf;
+        k2[j] = sm[C + c + j] / Mf;
+    }
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t nitems = (int64_t)N * Ho * Wo;
+    const int64_t i0 = slice_begin(items_per_block);
+    const int64_t i1 = min(nitems, i0 + items_per_block);
+    for (int64_t it = i0 + pl; it < i1; it += mp.PL) {
+        int xo, yo, n;
+        decode3(it, Wo, Ho, xo, yo, n);
+        const int64_t p00 = ((int64_t)n * H + 2 * yo) * W + 2 * xo;
+        const int64_t pix[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+        float zz[4][8], yy[4][8], g[4][8], dp[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unpack8(ld16(z + pix[k] * zp + c), zz[k]);
+            if (dy) unpack8(ld16(dy + pix[k] * dyp + c), g[k]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[k][j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t2 = zz[k][j] * sc[j] + sh[j];
+                yy[k][j] = bf2f(f2bf(relu ? fmaxf(t2, 0.f) : t2));   // what the forward compared
+            }
+        }
+        unpack8(ld16(dpool + it * dpp + c), dp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int best = 0;
+            float bv = yy[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (yy[k][j] > bv) { bv = yy[k][j]; best = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float gv = g[k][j] + (k == best ? dp[j] : 0.f);
+                if (relu && !(yy[k][j] > 0.f)) gv = 0.f;
+                gv = bf2f(f2bf(gv));                                 // the rounding of the stored intermediate
+                const float zh = (zz[k][j] - mu[j]) * is[j];
+                g[k][j] = k0[j] * (gv - k1[j] - zh * k2[j]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st16(dz + pix[k] * dzp + c, pack8(g[k]));
     }
 }
 
@@ -654,7 +737,6 @@ extern "C" int aau_bn_bwd_reduce(const aau_bf16* z, int z_pitch, const aau_bf16*
                                  float drop_p, const uint64_t* drop_seed, float* ws, void* stream) {
     AAU_REQUIRE(z && scale && shift && save_mean && save_invstd && red && ws, "aau_bn_bwd_reduce: null pointer");
     AAU_REQUIRE(((uintptr_t)ws & 15) == 0 && ((uintptr_t)red & 15) == 0, "aau_bn_bwd_reduce: red / ws must be 16-byte aligned");
-    AAU_REQUIRE(dz || !dpool, "aau_bn_bwd_reduce: the pooled form must store the masked gradient (dz != NULL)");
     AAU_REQUIRE(dy || dpool, "aau_bn_bwd_reduce: needs at least one gradient source");
     CHK_C("aau_bn_bwd_reduce", C);
     AAU_REQUIRE(z_pitch % 8 == 0 && dz_pitch % 8 == 0 && dy_pitch % 8 == 0 && dpool_pitch % 8 == 0,
@@ -708,6 +790,33 @@ extern "C" int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, in
                        dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, M, C, dy, dy_pitch, scale, shift,
                        relu, drop_p, drop_seed, (const float*)nullptr, (const float*)nullptr, ppb);
     return check_launch("aau_bn_bwd_apply");
+}
+
+extern "C" int aau_bn_bwd_apply_pool(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch, const float* gamma,
+                                     const float* save_mean, const float* save_invstd, const float* red, float* dgamma,
+                                     float* dbeta, int N, int H, int W, int C, const aau_bf16* dy, int dy_pitch,
+                                     const aau_bf16* dpool, int dpool_pitch, const float* scale, const float* shift,
+                                     int relu, void* stream) {
+    AAU_REQUIRE(z && dz && gamma && save_mean && save_invstd && red && dpool && scale && shift && N > 0 && H > 0 && W > 0,
+                "aau_bn_bwd_apply_pool: bad args");
+    AAU_REQUIRE(H % 2 == 0 && W % 2 == 0, "aau_bn_bwd_apply_pool: H=%d W=%d must be even", H, W);
+    AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_bn_bwd_apply_pool: pixel count overflows int32");
+    CHK_C("aau_bn_bwd_apply_pool", C);
+    AAU_REQUIRE(z_pitch % 8 == 0 && dz_pitch % 8 == 0 && dy_pitch % 8 == 0 && dpool_pitch % 8 == 0,
+                "aau_bn_bwd_apply_pool: pitches must be multiples of 8");
+    const CGMap mp(C);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    const int64_t items = (int64_t)N * (H / 2) * (W / 2);
+    int64_t blocks = (items + mp.PL * 2 - 1) / (mp.PL * 2);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    int64_t ipb = (items + blocks - 1) / blocks;
+    blocks = (items + ipb - 1) / ipb;
+    if (next_traversal()) ipb = -ipb;
+    hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, z,
+                       z_pitch, dz, dz_pitch, gamma, save_mean, save_invstd, red, dgamma, dbeta, N, H, W, C, dy, dy_pitch,
+                       dpool, dpool_pitch, scale, shift, relu, ipb);
+    return check_launch("aau_bn_bwd_apply_pool");
 }
 
 extern "C" int aau_bn_bwd_apply_rank1(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch, const float* gamma,

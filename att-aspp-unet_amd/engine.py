@@ -473,10 +473,18 @@ class Plan:
             b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
                   bn.dbeta, M, cv.O, dy, dyp, w["scale"], w["shift"], 1, dp_, self.drop_seed)
         else:
-            b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, dpool, dpp, dz, cv.O, w["scale"], w["shift"], w["mean"],
-                  w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed, self.red_ws)
-            b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
-                  bn.dbeta, M, cv.O, None, 0, None, None, 1, 0.0, self.drop_seed)
+            if self.eng.pool_store_routed:     # default: the reduce pass stores the routed gradient, the apply pass reads it
+                b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, dpool, dpp, dz, cv.O, w["scale"], w["shift"], w["mean"],
+                      w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed, self.red_ws)
+                b.add("aau_bn_bwd_apply", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"], bn.dgamma,
+                      bn.dbeta, M, cv.O, None, 0, None, None, 1, 0.0, self.drop_seed)
+            else:
+                # opt-in: both passes route the pooled gradient themselves, no intermediate tensor (2x2-window accesses in
+                # the apply pass cost more than the 1.25 tensor passes they save)
+                b.add("aau_bn_bwd_reduce", r["z"], cv.O, dy, dyp, dpool, dpp, None, cv.O, w["scale"], w["shift"], w["mean"],
+                      w["invstd"], w["red"], N, H, W, cv.O, 1, dp_, self.drop_seed, self.red_ws)
+                b.add("aau_bn_bwd_apply_pool", r["z"], cv.O, dz, cv.O, bn.gamma, w["mean"], w["invstd"], w["red"],
+                      bn.dgamma, bn.dbeta, N, H, W, cv.O, dy, dyp, dpool, dpp, w["scale"], w["shift"], 1)
         pad = cv.dil * (cv.k // 2)
         ov = self.eng.overlap_wgrad
         if ov:
@@ -888,6 +896,9 @@ class Engine:
         self.no_fuse_colsum = os.environ.get("AAU_NO_FUSE_COLSUM", "0") == "1"
         self.no_fuse_head = os.environ.get("AAU_NO_FUSE_HEAD", "0") == "1"
         self.no_wgrad_group = os.environ.get("AAU_NO_WGRAD_GROUP", "0") == "1"
+        # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
+        # reading the routed gradient the reduce pass stored
+        self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"
         # z of the first layer recomputed from the frame instead of stored (-201 MB of HBM at bs 8 / 512^2): measured
         # 0.08 ms SLOWER per step (the three recomputing kernels are VALU / latency bound, not byte bound), so opt-in
         self.no_recompute_z1 = os.environ.get("AAU_RECOMPUTE_Z1", "0") != "1" or self.no_fuse_conv1

@@ -245,6 +245,14 @@ def bn_bwd_apply(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, M, C
                                  sp, _stream()), "aau_bn_bwd_apply")
 
 
+def bn_bwd_apply_pool(z, zp, dz, dzp, gamma, smean, sinvstd, red, dgamma, dbeta, N, H, W, Cc, dy, dyp, dpool, dpp, scale,
+                      shift, relu=1):
+    """Apply pass of a pooled layer: redoes the max-pool routing (dy may be None), so bn_bwd_reduce needs no dz."""
+    check(fn("aau_bn_bwd_apply_pool")(_p(z), zp, _p(dz), dzp, _p(gamma), _p(smean), _p(sinvstd), _p(red), _p(dgamma),
+                                      _p(dbeta), N, H, W, Cc, _p(dy), dyp, _p(dpool), dpp, _p(scale), _p(shift), relu,
+                                      _stream()), "aau_bn_bwd_apply_pool")
+
+
 def bn_bwd_apply_conv1(z, zp, gamma, smean, sinvstd, red, dgamma, dbeta, N, H, W, Cc, dy, dyp, scale, shift, x, dw, ws,
                        w=None):
     """z None: recomputed from x and the conv weights ``w`` [C][9].  ws: None or >= bn_red_ws_bytes(Cc)."""

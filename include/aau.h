@@ -244,6 +244,14 @@ int aau_bn_bwd_apply(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
                      const float* red, float* dgamma, float* dbeta, int64_t M, int C,
                      const aau_bf16* dy, int dy_pitch, const float* scale, const float* shift,
                      int relu, float drop_p, const uint64_t* drop_seed, void* stream);
+/* Pooled layers (the encoder's second ConvBNReLU, pipeline:113-116 d1..d4 + MaxPool2d): the  */
+/* apply pass redoes the max-pool routing from dy (skip path, may be NULL), z and dpool, so  */
+/* the reduce pass may be called with dz = NULL there as well (no routed gradient stored).   */
+int aau_bn_bwd_apply_pool(const aau_bf16* z, int z_pitch, aau_bf16* dz, int dz_pitch,
+                          const float* gamma, const float* save_mean, const float* save_invstd,
+                          const float* red, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                          const aau_bf16* dy, int dy_pitch, const aau_bf16* dpool, int dpool_pitch,
+                          const float* scale, const float* shift, int relu, void* stream);
 
 /* First layer (pipeline:113 d1[0]): the apply pass fused with the weight gradient of its   */
 /* Conv2d(1, C, 3, pad 1) -- the layer has no input gradient, so dz is never written.     */

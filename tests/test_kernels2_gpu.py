@@ -114,6 +114,29 @@ def test_maxpool_and_bn_backward_with_pool_routing(ops, C):
     assert rel_err(dz.cpu(), zc.grad) < 2e-2
     assert rel_err(dgam.cpu(), gam.grad) < 1e-2
     assert rel_err(dbet.cpu(), bet.grad) < 1e-2
+    # the form the engine runs: neither pass stores the routed gradient, the apply pass redoes the routing -- same bits
+    red2 = zeros(ops.STAT_REPLICAS, 2, C)
+    ops.bn_bwd_reduce(zd, C, dev(bf(gy)), C, dev(bf(gp)), C, None, C, scale, shift, dev(mean.detach()), dev(invstd.detach()),
+                      red2, N, H, W, C, relu=1)
+    dz2 = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dgam2, dbet2 = zeros(C), zeros(C)
+    ops.bn_bwd_apply_pool(zd, C, dz2, C, dev(gamma), dev(mean.detach()), dev(invstd.detach()), red2, dgam2, dbet2, N, H, W, C,
+                          dev(bf(gy)), C, dev(bf(gp)), C, scale, shift, relu=1)
+    torch.cuda.synchronize()
+    assert torch.equal(red2, red)
+    assert torch.equal(dz2.view(torch.int16), dz.view(torch.int16))
+    assert torch.equal(dgam2, dgam) and torch.equal(dbet2, dbet)
+    # no skip path (dy = NULL): only the pooled gradient arrives
+    red3 = zeros(ops.STAT_REPLICAS, 2, C)
+    dz3a = zeros(N, H, W, C, dtype=torch.bfloat16)
+    ops.bn_bwd_reduce(zd, C, None, 0, dev(bf(gp)), C, dz3a, C, scale, shift, dev(mean.detach()), dev(invstd.detach()),
+                      red3, N, H, W, C, relu=1)
+    ops.bn_bwd_apply(zd, C, dz3a, C, dev(gamma), dev(mean.detach()), dev(invstd.detach()), red3, zeros(C), zeros(C), N * H * W, C)
+    dz3b = zeros(N, H, W, C, dtype=torch.bfloat16)
+    ops.bn_bwd_apply_pool(zd, C, dz3b, C, dev(gamma), dev(mean.detach()), dev(invstd.detach()), red3, zeros(C), zeros(C), N, H, W,
+                          C, None, 0, dev(bf(gp)), C, scale, shift, relu=1)
+    torch.cuda.synchronize()
+    assert torch.equal(dz3a.view(torch.int16), dz3b.view(torch.int16))
     # no-pool variant (plain BN + ReLU backward)
     zc2 = z.clone().requires_grad_(True)
     flat2 = zc2.reshape(-1, C)
