@@ -409,7 +409,10 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
                 if (q < d.Cout) {
                     if (want_stats) {      // rows past M hold zeros (their loads were out of range)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { s1[ni][r] += va[r] + vb[r]; s2[ni][r] += va[r] * va[r] + vb[r] * vb[r]; }
+                        for (int r = 0; r < 4; ++r) {     // in the order of the 8-byte form: same bits
+                            s1[ni][r] += va[r]; s2[ni][r] += va[r] * va[r];
+                            s1[ni][r] += vb[r]; s2[ni][r] += vb[r] * vb[r];
+                        }
                     }
                     const int qv = d.shuffle2x2 ? q % Co : q;
                     if (a.bias) {

@@ -262,3 +262,33 @@ def test_training_step_is_bitwise_reproducible(A):
     for k in a[5]:
         assert torch.equal(a[5][k], b[5][k]), k
     assert a[0][2] < a[0][0]
+
+
+@pytest.mark.parametrize("switch", ["AAU_POOL_APPLY_ROUTES", "AAU_NO_IGEMM_GROUP", "AAU_NO_WIDE_STORE", "AAU_RESW_NOPAIR"])
+def test_experiment_switches_do_not_change_the_result(A, switch, monkeypatch):
+    """The opt-in / ablation forms of this round's kernels compute the same step: the pooled apply pass that redoes the
+    max-pool routing is bitwise identical; the ungrouped bridge input gradient, the 8-byte epilogue stores and the
+    unpaired Cin % 32 <= 16 chunk only change the order of fp32 additions (or nothing at all)."""
+    from att_aspp_unet_amd import synth
+    args = Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05)
+    x, y = synth.make_frames(4, 128, seed=5, force_pattern="ppnp")
+    x, y = x.cuda(), y.cuda()
+
+    def run():
+        torch.manual_seed(3)
+        m = A.AttentionASPPUNet(base_c=24).cuda().train()     # bridge 192 -> 384: the grouped input gradient applies
+        m.engine.set_drop_p(0.0) if hasattr(m.engine, "set_drop_p") else None
+        opt = A.FusedAdamW(m, lr=1e-3)
+        step = A.TrainStep(m, opt, args)
+        loss = float(step(x, y))
+        return loss, m.engine.store.gflat.clone()
+
+    la, ga = run()
+    monkeypatch.setenv(switch, "1")
+    lb, gb = run()
+    if switch in ("AAU_POOL_APPLY_ROUTES", "AAU_NO_WIDE_STORE"):
+        assert la == lb and torch.equal(ga, gb)
+    else:
+        assert abs(la - lb) <= 1e-5 * abs(la)
+        cos = torch.nn.functional.cosine_similarity(ga, gb, dim=0)
+        assert float(cos) > 0.9999 and abs(float(ga.norm() / gb.norm()) - 1) < 1e-3
