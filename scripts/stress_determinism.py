@@ -59,4 +59,35 @@ tot += run_wgrad("wgrad3x3 512 48->48", 8, 512, 512, 48, 48, 3, 1)
 tot += run_wgrad("wgrad3x3 64 768->384", 8, 64, 64, 768, 384, 3, 1)
 tot += run_wgrad("wgrad 1x1 256 96->48", 8, 256, 256, 96, 48, 1, 1)
 tot += run_wgrad("wgrad dil6 32 384->768", 8, 32, 32, 384, 768, 3, 6)
+
+
+def run_group(name, reps=30):
+    """grouped bridge input gradient (igemm_group.hip): register-staged ring, two K-ranges, fixed-order slab sum"""
+    B, H, Ci, Co = 8, 32, 768, 384
+    segs = [(1, 1), (3, 6), (3, 12), (3, 18)]
+    descs, srcs, wpks = [], [], []
+    for i, (k, dil) in enumerate(segs):
+        srcs.append(torch.randn(B, H, H, Ci, device="cuda").to(torch.bfloat16))
+        wpks.append((torch.randn(Co, k * k, Ci, device="cuda") / (Ci * k * k) ** 0.5).to(torch.bfloat16))
+        descs.append(ops.conv_desc(B, H, H, Ci, Ci, H, H, Co, Co, k, k, 1, dil * (k // 2), dil, Ci, accumulate=1 if i else 0))
+    ws = torch.full((ops.conv_igemm_group_ws_bytes(descs) // 4,), float("nan"), device="cuda")
+    other = torch.randn(64 << 20, device="cuda")
+    outs = []
+    for r in range(reps):
+        out = torch.full((B, H, H, Co), float("nan"), dtype=torch.bfloat16, device="cuda")
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_igemm_group(descs, srcs, wpks, out, ws)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(out)
+    torch.cuda.synchronize()
+    bad = sum(0 if torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) else 1 for o in outs[1:])
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0].float()).sum())}", flush=True)
+    return bad
+
+
+tot += run_group("igemm_group bridge dgrad")
+tot += run_case("igemm wide convT-like 768->1536", 8, 32, 32, 768, 1536, 1, 1)
+tot += run_case("igemm wide dil18 384->768", 8, 32, 32, 384, 768, 3, 18)
+tot += run_case("resw2 paired 512 48->48", 8, 512, 512, 48, 48, 3, 1, reps=12)
+tot += run_case("conv1x1_resw 256 96->48", 8, 256, 256, 96, 48, 1, 1, reps=12)
 print("TOTAL mismatches", tot)
