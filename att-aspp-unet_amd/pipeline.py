@@ -502,3 +502,14 @@ def get_args(argv=None):
     ca.add_argument("--output_dir", default="./checkpoints"); ca.add_argument("--base_c", type=int, default=48)
     ca.add_argument("--precision", choices=["fp16", "bf16"], default="fp16")
     return p.parse_args(argv)
+
+
+def main(argv=None):
+    """pipeline:552-556: dispatch of the three sub-commands."""
+    args = get_args(argv)
+    if args.cmd == "train":
+        return train(args)
+    if args.cmd == "predict":
+        return predict(args)
+    if args.cmd == "calibrate":
+        return calibrate(args)

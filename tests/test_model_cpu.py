@@ -63,3 +63,23 @@ def test_lr_schedule_matches_oracle_closed_form():
     for stage, ep in (("main", 120), ("finetune", 40)):
         for e in range(ep):
             assert A.lr_at_epoch(e, ep, 3e-4, stage) == pytest.approx(O.lr_at_epoch(e, ep, 3e-4, stage), rel=1e-12)
+
+
+def test_command_line_of_the_reference_script():
+    """attention_aspp_unet_pipeline_stage.py:538-556: train / predict / calibrate sub-commands with the reference's flags
+    (``python -m att_aspp_unet_amd <cmd> ...``).  Parsing only: running them needs a GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cmd, flags in (("train", ["--stage", "--train_dir", "--neg_dir", "--val_dir", "--output_dir", "--pretrained", "--epochs",
+                                  "--batch_size", "--lr", "--base_c", "--edge_w", "--neg_bce_w", "--seed"]),
+                       ("predict", ["--weights", "--input_dir", "--out_dir", "--spacing_json", "--base_c"]),
+                       ("calibrate", ["--weights", "--val_dir", "--output_dir", "--base_c"])):
+        r = subprocess.run([sys.executable, "-m", "att_aspp_unet_amd", cmd, "--help"], cwd=root, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-400:]
+        for f in flags:
+            assert f in r.stdout, (cmd, f)
+    r = subprocess.run([sys.executable, "-m", "att_aspp_unet_amd", "predict"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "required" in r.stderr
