@@ -43,8 +43,12 @@ struct W3RArgs {
 
 #define AAU_TR16O(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 
-template <int QT, int CJ>
-__global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
+// KG = 2: the workgroup is TWO such four-wave groups on alternate patches of its K-range, each with its own pair of
+// staging buffers, combined through LDS (group 1 -> group 0, a fixed order) before the slab leaves.  The same eight
+// waves per CU as two KG = 1 workgroups, but half as many split-K slabs: every launch used to write 56 MB of partial
+// sums (512 workgroups x 110 KB, whatever the layer) that wg_reduce_kernel read back.
+template <int QT, int CJ, int KG>
+__global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a) {
     static_assert(CJ * (QT / 3) == 4 && QT % 3 == 0, "four waves: CJ channel groups x QT/3 q groups");
     constexpr int BQ = QT * 16, BC = CJ * 16;
     constexpr int PR = 8, NPX = PR * 16;                  // pixels per K-step
@@ -60,12 +64,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_r[];
-    unsigned char* smem = smem_r;
 
     const aau_conv_desc& d = a.d;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int grp = (KG == 2) ? (wave8 >> 2) : 0;           // K-group
+    const int wave = wave8 & 3;                             // wave within the group
+    const int tid = (int)threadIdx.x & 255;                 // thread within the group
     const int lane = tid & 63;
+    unsigned char* smem = smem_r + grp * 2 * STAGE;
     const int jw = wave % CJ, qg = wave / CJ;
 
     const int ntc = (d.Cin + BC - 1) / BC;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
     const int p_begin = split * a.patches_per_block;
     const int p_end = min(a.npatch, p_begin + a.patches_per_block);
     if (p_begin >= p_end) {   // never taken with the host's split sizes, but a slab must not stay unwritten
-        if (a.ws)
+        if (a.ws && grp == 0)
             for (int v = 0; v < 27; ++v)
                 *(f32x4*)(a.ws + ((int64_t)lbid * 27 * 256 + v * 256 + tid) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
@@ -129,16 +135,17 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
         const int n = t2 / a.tiles_y;
         const int y0 = pyi * PR, x0 = pxi * 16;
         const int org = ((n * d.H + y0) * d.W + x0);          // pixel index of the patch origin (scalar)
+        const bool live = patch < p_end;                      // a group's padding trip (KG = 2, odd patch count): zeros
         unsigned char* sy = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < NLY; ++i) {
-            const unsigned v = yrel[i] >= 0 ? (unsigned)((org * d.dst_pitch + yrel[i]) * 2) : OOB;
+            const unsigned v = (live && yrel[i] >= 0) ? (unsigned)((org * d.dst_pitch + yrel[i]) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sy + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
             const int y = y0 - 1 + xhy[i], x = x0 - 1 + xhx[i];
-            const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
+            const bool ok = live && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
             const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + xch[i]) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sy + YB + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
         }
@@ -224,25 +231,50 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_kernel(const W3RArgs a) {
     };
 
     // two patches per loop trip so that the stage index is a compile-time constant in every LDS address
-    int patch = p_begin;
+    // group g takes patches p_begin + g, p_begin + g + KG, ...; both groups run the same number of trips (the barriers
+    // are workgroup wide), a trip past p_end stages zeros
+    const int ntrip = (p_end - p_begin + KG - 1) / KG;
+    int patch = p_begin + grp, k = 0;
     stage(0, patch);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     while (true) {
-        bool more = patch + 1 < p_end;
-        if (more) stage(1, patch + 1);
+        bool more = k + 1 < ntrip;
+        if (more) stage(1, patch + KG);
         compute(0);
         if (!more) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        ++patch;
-        more = patch + 1 < p_end;
-        if (more) stage(0, patch + 1);
+        patch += KG; ++k;
+        more = k + 1 < ntrip;
+        if (more) stage(0, patch + KG);
         compute(1);
         if (!more) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        ++patch;
+        patch += KG; ++k;
+    }
+    if constexpr (KG == 2) {
+        if (a.ws) {     // group 1 hands its 27 accumulator tiles to group 0 through LDS (the staging buffers are dead)
+            f32x4* comb = (f32x4*)smem_r;
+            __syncthreads();
+            if (grp == 1) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int u = 0; u < 3; ++u) comb[((i * 3 + t) * 3 + u) * 256 + tid] = acc[i][t][u];
+            }
+            __syncthreads();
+            if (grp == 1) return;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) acc[i][t][u] += comb[((i * 3 + t) * 3 + u) * 256 + tid];
+        }
     }
 
     // acc[i][tx][ty][r] = D[q = q0 + (qg*3 + i)*16 + 4*g16 + r][tap = ty*3 + tx][c = c0 + jw*16 + li]
@@ -286,7 +318,7 @@ int wgrad3x3r_variant(const aau_conv_desc* d) {
     return 0;
 }
 
-template <int QT, int CJ>
+template <int QT, int CJ, int KG>
 static int launch_w3r(W3RArgs& a, const aau_conv_desc* d, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
     constexpr int BQ = QT * 16, BC = CJ * 16;
     constexpr int YB = ((128 * (BQ / 8) + 255) / 256) * 4096, XB = ((180 * CJ * 2 + 255) / 256) * 4096;
@@ -295,11 +327,11 @@ static int launch_w3r(W3RArgs& a, const aau_conv_desc* d, float* ws, int64_t ws_
     a.npatch = d->N * a.tiles_x * a.tiles_y;
     const int ntc = (d->Cin + BC - 1) / BC;
     const int64_t tiles = (int64_t)((d->Cout + BQ - 1) / BQ) * ntc;
-    int64_t target = 512;                                   // one resident round (2 workgroups per CU), see wgrad3x3.hip
+    int64_t target = 512 / KG;                              // one resident round (8 waves per CU), see wgrad3x3.hip
     if (const char* e = getenv("AAU_W3_TARGET")) target = atoi(e);   // experiment
     int64_t nsplit = target / tiles;                         // never more workgroups than resident slots: a second
                                                              // round of a few workgroups doubles the launch time
-    const int64_t maxsplit = (a.npatch + 3) / 4;             // at least 4 K-steps per workgroup
+    const int64_t maxsplit = (a.npatch + 4 * KG - 1) / (4 * KG);   // at least 4 K-steps per four-wave group
     if (nsplit > maxsplit) nsplit = maxsplit;
     if (nsplit < 1) nsplit = 1;
     a.patches_per_block = (int)((a.npatch + nsplit - 1) / nsplit);
@@ -317,10 +349,11 @@ static int launch_w3r(W3RArgs& a, const aau_conv_desc* d, float* ws, int64_t ws_
     a.noremap = getenv("AAU_W3_NOREMAP") ? 1 : 0;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)wgrad3x3r_kernel<QT, CJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)wgrad3x3r_kernel<QT, CJ, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((wgrad3x3r_kernel<QT, CJ>), dim3((unsigned)grid), dim3(256), 2 * (YB + XB), s, a);
+    static_assert(KG == 1 || KG * 2 * (YB + XB) >= 27 * 256 * 16, "the combine needs 27 x 256 float4 of LDS");
+    hipLaunchKernelGGL((wgrad3x3r_kernel<QT, CJ, KG>), dim3((unsigned)grid), dim3(256 * KG), KG * 2 * (YB + XB), s, a);
     if (!ws) return check_launch("aau_conv_wgrad(3x3 row reuse)");
     WRedArgs r;
     r.ws = ws; r.dw = a.dw;
@@ -340,8 +373,18 @@ int wgrad3x3r_launch(int variant, const aau_conv_desc* d, const aau_bf16* src, c
     if (sb >= 0x7fffffff || zb >= 0x7fffffff) { set_error("aau_conv_wgrad: tensors must stay below 2 GiB"); return AAU_E_INVALID; }
     a.src_bytes = (unsigned)sb;
     a.dz_bytes = (unsigned)zb;
-    if (variant == 1) return launch_w3r<3, 4>(a, d, ws, ws_bytes, need, s);
-    return launch_w3r<6, 2>(a, d, ws, ws_bytes, need, s);
+    static const bool kg1env = getenv("AAU_W3_KG1") != nullptr;    // experiment: one four-wave group per workgroup
+    // two K-groups only where whole K-ranges still fill the chip: with 96 tiles (768 -> 384 channels) 256 / 96 = 2 ranges
+    // leave a quarter of the CUs idle, the five ranges of the one-group form 6 %
+    const int BQv = variant == 1 ? 48 : 96, BCv = variant == 1 ? 64 : 32;
+    const int64_t tiles_v = (int64_t)((d->Cout + BQv - 1) / BQv) * ((d->Cin + BCv - 1) / BCv);
+    const bool kg1 = kg1env || (256 / tiles_v) * tiles_v < 230;
+    if (kg1) {
+        if (variant == 1) return launch_w3r<3, 4, 1>(a, d, ws, ws_bytes, need, s);
+        return launch_w3r<6, 2, 1>(a, d, ws, ws_bytes, need, s);
+    }
+    if (variant == 1) return launch_w3r<3, 4, 2>(a, d, ws, ws_bytes, need, s);
+    return launch_w3r<6, 2, 2>(a, d, ws, ws_bytes, need, s);
 }
 
 }  // namespace aau
