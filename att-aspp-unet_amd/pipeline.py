@@ -294,7 +294,8 @@ def train(args, train_loader=None, val_loader=None):
 
     Data parallel: when ``torch.distributed`` is initialised with more than one rank (one process per GPU, launched by
     ``python -m torch.distributed.run``), the model is wrapped in ``parallel.DataParallel``: every rank trains on its
-    own shard (the synthetic loader is seeded per rank; a caller-supplied loader must shard itself), gradients are
+    own shard (the synthetic loader is seeded per rank, the directory loader deals the shuffled frames out by rank; a
+    caller-supplied loader must shard itself), gradients are
     all-reduced in buckets under the backward pass, and every rank applies the same update.  Validation runs on every
     rank over the same set (identical decisions everywhere); rank 0 alone prints and writes checkpoints."""
     import torch.distributed as dist
@@ -305,11 +306,15 @@ def train(args, train_loader=None, val_loader=None):
     device = torch.device("cuda", torch.cuda.current_device())
     if train_loader is None:
         n = int(getattr(args, "synthetic_batches", 0) or 0)
-        if n <= 0:
-            raise RuntimeError("no dataset reader on this machine (cv2/albumentations absent): pass loaders or --synthetic_batches N")
         size = int(getattr(args, "img_size", IMG_SIZE))
-        train_loader = SyntheticLoader(n, args.batch_size, size, args.seed + 7919 * rank, device)
-        val_loader = SyntheticLoader(max(1, n // 10), args.batch_size, size, args.seed + 100000, device, neg_frac=0.0)
+        if n > 0:
+            train_loader = SyntheticLoader(n, args.batch_size, size, args.seed + 7919 * rank, device)
+            val_loader = SyntheticLoader(max(1, n // 10), args.batch_size, size, args.seed + 100000, device, neg_frac=0.0)
+        elif getattr(args, "train_dir", None):
+            from . import dataset            # pipeline:248-295: images/ + masks/ directories, decoded by PIL, transformed on the GPU
+            train_loader, val_loader = dataset.loaders_from_args(args, device, rank, world)
+        else:
+            raise RuntimeError("train needs --train_dir (images/ + masks/), --synthetic_batches N, or loaders passed in")
     model = AttentionASPPUNet(base_c=args.base_c).to(device)
     if args.stage == "finetune":
         load_state_dict_compat(model, args.pretrained)
