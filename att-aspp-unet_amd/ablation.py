@@ -127,7 +127,8 @@ def train(args, train_loader=None, val_loader=None):
     ``att_depth``, attention parameters at twice the backbone's learning rate (:576-586), warm-up + cosine schedule,
     ``--no_edge_loss``, per-epoch train / validation loss, Dice and IoU written to ``metrics.csv`` (:605-609), best
     checkpoint by validation Dice, early stopping.  bf16 activations with fp32 master weights replace fp16 autocast +
-    GradScaler; the loaders are any iterables of ``(x, y)`` batches (synthetic phantoms with ``--synthetic_batches N``)."""
+    GradScaler; the loaders are any iterables of ``(x, y)`` batches (``--train_dir`` directories through ``dataset.py``,
+    synthetic phantoms with ``--synthetic_batches N``)."""
     import csv
     from datetime import datetime
     from pathlib import Path
@@ -139,11 +140,15 @@ def train(args, train_loader=None, val_loader=None):
     device = torch.device("cuda", torch.cuda.current_device())
     if train_loader is None:
         n = int(getattr(args, "synthetic_batches", 0) or 0)
-        if n <= 0:
-            raise RuntimeError("no dataset reader on this machine (cv2/albumentations absent): pass loaders or --synthetic_batches N")
         size = int(getattr(args, "img_size", IMG_SIZE))
-        train_loader = SyntheticLoader(n, args.batch_size, size, args.seed, device)
-        val_loader = SyntheticLoader(max(1, n // 10), args.batch_size, size, args.seed + 100000, device, neg_frac=0.0)
+        if n > 0:
+            train_loader = SyntheticLoader(n, args.batch_size, size, args.seed, device)
+            val_loader = SyntheticLoader(max(1, n // 10), args.batch_size, size, args.seed + 100000, device, neg_frac=0.0)
+        elif getattr(args, "train_dir", None):
+            from . import dataset            # the same images/ + masks/ directories as the main script
+            train_loader, val_loader = dataset.loaders_from_args(args, device)
+        else:
+            raise RuntimeError("train needs --train_dir (images/ + masks/), --synthetic_batches N, or loaders passed in")
     model = AttentionASPPUNet(base_c=args.base_c, use_att=not getattr(args, "no_att", False),
                               use_aspp=not getattr(args, "no_aspp", False), att_depth=getattr(args, "att_depth", 4)).to(device)
     if args.stage == "finetune":
