@@ -12,7 +12,7 @@ from .optim import FusedAdamW  # noqa: F401
 from .pipeline import (EARLY_STOP_PATIENCE, GRAD_CLIP, IMG_SIZE, SEED, WEIGHT_DECAY, GraphedForward, GraphedTrainStep, SyntheticLoader,  # noqa: F401
                        TrainStep, evaluate, get_args, load_state_dict_compat, lr_at_epoch, predict_prob_tta, predict_sliding_window, set_seed,
                        train)
-from . import ablation, dataset, evalseg, gc_wrapper, imgproc, measure  # noqa: F401
+from . import ablation, dataset, evalseg, gc_wrapper, imgproc, measure, mhaio  # noqa: F401
 from .measure import measure_ac_mm, select_best  # noqa: F401
 from .imgproc import refine_mask  # noqa: F401
 from .pipeline import calibrate, predict, predict_masks, predict_prob_tta_batch  # noqa: F401

@@ -7,8 +7,8 @@ Files are decoded on the host with PIL (cv2 is not installed here; for single-ch
 transform -- Resize(512) -> CLAHE(1.0, 8x8) -> MedianBlur(3) -> ToFloat(255) (``imgproc.preprocess_frames(...,
 resize_first=True)``; masks: nearest resize, /255) -- and, for training, HorizontalFlip(0.5) and the shuffle, both drawn
 from a seeded torch generator.  The other random augmentations of the reference (Affine, RandomGamma,
-RandomBrightnessContrast, ElasticTransform: albumentations' own samplers and RNG stream) are not reproduced; ``.mha``
-volumes need SimpleITK and are skipped with a warning.
+RandomBrightnessContrast, ElasticTransform: albumentations' own samplers and RNG stream) are not reproduced.  ``.mha``
+volumes are read by ``mhaio.py`` (middle slice, as the reference does).
 """
 from __future__ import annotations
 
@@ -50,10 +50,14 @@ def split_train_val(imgs: Sequence[Path], msks: Sequence[Optional[Path]], seed: 
 
 
 def read_gray(path) -> Optional[np.ndarray]:
-    """uint8 [H, W]; None for formats this machine cannot decode (.mha)."""
+    """uint8 [H, W]; of an .mha volume the middle slice (pipeline:160-162)."""
     path = Path(path)
     if path.suffix.lower() == ".mha":
-        return None
+        from . import mhaio
+        arr, _ = mhaio.read(path)
+        if arr.ndim == 3:
+            arr = arr[arr.shape[0] // 2]
+        return np.ascontiguousarray(arr.astype(np.uint8))
     from PIL import Image
     return np.array(Image.open(path).convert("L"), dtype=np.uint8)
 
@@ -64,11 +68,8 @@ class DirectoryLoader:
 
     def __init__(self, imgs: Sequence[Path], msks: Sequence[Optional[Path]], batch_size: int, size: int = 512, train: bool = True,
                  seed: int = 2025, device="cuda", rank: int = 0, world: int = 1):
-        keep = [i for i, p in enumerate(imgs) if Path(p).suffix.lower() != ".mha"]
-        if len(keep) != len(imgs):
-            print(f"dataset: skipping {len(imgs) - len(keep)} .mha file(s) (SimpleITK is not available)")
-        self.imgs = [Path(imgs[i]) for i in keep]
-        self.msks = [msks[i] for i in keep]
+        self.imgs = [Path(p) for p in imgs]
+        self.msks = list(msks)
         self.bs, self.size, self.train, self.device = int(batch_size), int(size), bool(train), torch.device(device)
         self.rank, self.world = int(rank), int(world)
         self.gen = torch.Generator().manual_seed(int(seed))

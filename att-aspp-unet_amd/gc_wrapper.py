@@ -25,12 +25,9 @@ __all__ = ["FetalAbdomenSegmentation", "select_fetal_abdomen_mask_and_frame", "l
 
 
 def load_image_file_as_array(*, location: Path):
-    """model_attention_aspp.py:14-18 (SimpleITK read, then the GPU preprocessing) -> fp32 [1, F, H, W] on the device."""
-    try:
-        import SimpleITK
-    except ImportError as e:       # the reader is a file-format dependency, not part of the hot path
-        raise RuntimeError("reading .mha needs SimpleITK; use predict_array(uint8 [F,H,W]) instead") from e
-    arr = SimpleITK.GetArrayFromImage(SimpleITK.ReadImage(str(location)))
+    """model_attention_aspp.py:14-18 (MetaImage read, then the GPU preprocessing) -> fp32 [1, F, H, W] on the device."""
+    from . import mhaio            # MetaImage container read without SimpleITK
+    arr, _ = mhaio.read(location)
     return preprocess_sweep(torch.from_numpy(np.ascontiguousarray(arr.astype(np.uint8))).cuda())[None]
 
 
@@ -70,13 +67,10 @@ class FetalAbdomenSegmentation:
         return imgproc.roi_paste_sigmoid(logits, org, (H, W)), idxs
 
     def predict(self, input_img_path, save_probabilities=False):
-        """:40-64 on an .mha path (needs SimpleITK for the file format) -> numpy [128, H, W]."""
-        try:
-            import SimpleITK
-        except ImportError as e:
-            raise RuntimeError("reading .mha needs SimpleITK; use predict_array(uint8 [F,H,W]) instead") from e
+        """:40-64 on an .mha path (read by mhaio.py) -> numpy [128, H, W]."""
+        from . import mhaio
         self.case_id = Path(input_img_path[0]).stem
-        arr = SimpleITK.GetArrayFromImage(SimpleITK.ReadImage(str(input_img_path[0])))
+        arr, _ = mhaio.read(input_img_path[0])
         prob, _ = self.predict_array(arr.astype(np.uint8))
         return prob.cpu().numpy()
 

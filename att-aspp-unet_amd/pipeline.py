@@ -151,8 +151,8 @@ def calibrate(args):
 def predict(args):
     """pipeline:399-523 for PNG / JPG inputs: one mask PNG per slice, computed GPU-resident (``predict_masks``), and --
     when ``--spacing_json`` names the case -- its abdominal circumference (``measure.measure_ac_mm``, :359-374) collected
-    into ``ac_results.csv`` (:517-523).  ``.mha`` sweeps (SimpleITK reader / writer, :485-515) are a file format outside
-    the hot path: use ``predict_masks`` + ``measure.select_best`` on the decoded frames."""
+    into ``ac_results.csv`` (:517-523).  ``.mha`` sweeps (:483-511) are read and written by ``mhaio.py``: every frame is
+    segmented, ``measure.select_best`` picks the frame, ``output.mha`` + the frame-number JSON are written."""
     import csv
     import json
     from PIL import Image
@@ -189,6 +189,29 @@ def predict(args):
     od.mkdir(exist_ok=True, parents=True)
     done, rows = [], []
     for p in sorted(Path(args.input_dir).iterdir()):
+        if p.suffix.lower() == ".mha":
+            # pipeline:483-511: every frame of the sweep, the most circular of the five largest masks, the output volume
+            # (mask value 2 in that frame) + frame-number JSON, AC with the spacing of the file's own header
+            from . import mhaio
+            vol, hdr = mhaio.read(p)
+            if vol.ndim == 2:
+                vol = vol[None]
+            if vol.dtype != np.uint8:
+                # cv2.normalize(sl, None, 0, 255, NORM_MINMAX).astype(uint8) per slice (:491) in the file's own type; the
+                # uint8 normalisation inside predict_masks is then the identity
+                v = vol.astype(np.float64)
+                lo, hi = v.min((1, 2), keepdims=True), v.max((1, 2), keepdims=True)
+                vol = np.clip(np.rint((v - lo) * (255.0 / np.where(hi > lo, hi - lo, 1.0))), 0, 255).astype(np.uint8)
+            preds = predict_masks(model, np.ascontiguousarray(vol), thr)        # uint8 [N,H,W] on the device
+            bf = measure.select_best(preds, 5)
+            bm = preds[bf].cpu().numpy()
+            write_output_mha_and_json(bm, bf, p, od, hdr, vol.shape[0])
+            sp3 = mhaio.spacing(hdr)
+            ac_mm = round(measure.measure_ac_mm(bm, (float(sp3[0]), float(sp3[1]))), 1)
+            rows.append((p.stem, int(bf), ac_mm))
+            done.append(p.stem)
+            print(f"{p.stem}: best_frame={bf}, AC={ac_mm:.1f} mm")
+            continue
         if p.suffix.lower() not in {".png", ".jpg", ".jpeg"}:
             continue
         mask = predict_masks(model, _read_gray(p), thr)[0]
@@ -215,6 +238,33 @@ def predict(args):
             w.writerow(["case_id", "frame_idx", "ac_mm"])
             w.writerows(rows)
     return done
+
+
+def convert_mask_2d_to_3d(mask, frame, nf):
+    """pipeline:526-529: the 2-D mask as value 2 in frame ``frame`` of an otherwise empty volume of ``nf`` frames."""
+    m = (np.asarray(mask) > 0).astype(np.uint8) * 2
+    vol = np.zeros((nf,) + m.shape, np.uint8)
+    if 0 <= frame < nf:
+        vol[frame] = m
+    return vol
+
+
+def write_output_mha_and_json(mask, frame, ref, od, ref_header=None, nf=None):
+    """pipeline:530-536: ``<od>/<case>/images/fetal-abdomen-segmentation/output.mha`` with the reference volume's geometry
+    and ``<od>/<case>/fetal-abdomen-frame-number.json``."""
+    import json
+    from . import mhaio
+    ref = Path(ref)
+    if ref_header is None or nf is None:
+        ref_header, _ = mhaio.read_header(ref)
+        dims = [int(t) for t in ref_header["DimSize"].split()]
+        nf = dims[2] if len(dims) > 2 else 1
+    cd = Path(od) / ref.stem
+    (cd / "images" / "fetal-abdomen-segmentation").mkdir(parents=True, exist_ok=True)
+    mhaio.write(cd / "images" / "fetal-abdomen-segmentation" / "output.mha", convert_mask_2d_to_3d(mask, int(frame), int(nf)),
+                like=ref_header)
+    json.dump(int(frame), open(cd / "fetal-abdomen-frame-number.json", "w"), indent=2)
+    print(f"{ref.stem} frame {int(frame)}")
 
 
 class GraphedForward:

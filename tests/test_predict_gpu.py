@@ -57,3 +57,61 @@ def test_select_best_on_a_device_stack_matches_the_host():
     stack = np.stack([(((yy - 80) / a) ** 2 + ((xx - 80) / b) ** 2 < 1).astype(np.uint8)
                       for a, b in [(70, 20), (40, 38), (60, 30), (10, 10), (50, 45), (66, 33)]])
     assert measure.select_best(torch.from_numpy(stack).cuda(), topk=4) == measure.select_best(stack, topk=4)
+
+
+def test_predict_on_an_mha_sweep_writes_the_output_volume(tmp_path):
+    """pipeline:483-511,526-536: every frame segmented, select_best, output.mha (value 2 in the chosen frame, geometry of
+    the input), the frame-number JSON and the AC row with the spacing of the file's header."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import att_aspp_unet_amd as A
+    from att_aspp_unet_amd import measure, mhaio, pipeline
+    rng = np.random.default_rng(8)
+    yy, xx = np.mgrid[0:112, 0:144]
+    vol = np.stack([np.clip(40 + 150 * (((yy - 56) / (20 + 4 * k)) ** 2 + ((xx - 72) / (30 + 3 * k)) ** 2 < 1) + rng.normal(0, 10, yy.shape),
+                            0, 255).astype(np.uint8) for k in range(6)])
+    inp = tmp_path / "in"
+    inp.mkdir()
+    like = {"ElementSpacing": "0.3 0.45 1", "Offset": "5 6 7"}
+    mhaio.write(inp / "sweepA.mha", vol, like=like)
+    mhaio.write(inp / "sweepB.mha", vol.astype(np.int16) * 3 - 100, like=like, compress=False)   # another element type
+    torch.manual_seed(0)
+    net = A.AttentionASPPUNet(base_c=8).cuda()
+    torch.save(net.state_dict(), tmp_path / "w.pth")
+    json.dump({}, open(tmp_path / "sp.json", "w"))
+    args = types.SimpleNamespace(weights=str(tmp_path / "w.pth"), input_dir=str(inp), out_dir=str(tmp_path / "out"),
+                                 spacing_json=str(tmp_path / "sp.json"), base_c=8, precision="fp16")
+    done = pipeline.predict(args)
+    assert sorted(done) == ["sweepA", "sweepB"]
+    rows = {r[0]: r for r in list(csv.reader(open(tmp_path / "out" / "ac_results.csv")))[1:]}
+    for case in ("sweepA", "sweepB"):
+        out, h = mhaio.read(tmp_path / "out" / case / "images" / "fetal-abdomen-segmentation" / "output.mha")
+        bf = json.load(open(tmp_path / "out" / case / "fetal-abdomen-frame-number.json"))
+        assert out.shape == vol.shape and out.dtype == np.uint8 and set(np.unique(out)) <= {0, 2}
+        assert mhaio.spacing(h) == (0.3, 0.45, 1.0) and h["Offset"] == "5 6 7"
+        assert all(out[k].max() == 0 for k in range(6) if k != bf)
+        assert int(rows[case][1]) == bf
+        assert float(rows[case][2]) == round(measure.measure_ac_mm((out[bf] > 0).astype(np.uint8), (0.3, 0.45)), 1)
+    # the int16 sweep is an affine map of the uint8 one: per-slice min-max normalisation makes the inputs identical
+    a, _ = mhaio.read(tmp_path / "out" / "sweepA" / "images" / "fetal-abdomen-segmentation" / "output.mha")
+    b, _ = mhaio.read(tmp_path / "out" / "sweepB" / "images" / "fetal-abdomen-segmentation" / "output.mha")
+    assert np.array_equal(a, b)
+    # the frame choice is select_best over the per-frame masks the device path produces
+    masks = pipeline.predict_masks(net.eval().set_precision("fp16"), vol, 0.48)
+    assert measure.select_best(masks, 5) == json.load(open(tmp_path / "out" / "sweepA" / "fetal-abdomen-frame-number.json"))
+
+
+def test_gc_wrapper_reads_mha(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from att_aspp_unet_amd import gc_wrapper, mhaio
+    rng = np.random.default_rng(1)
+    vol = (rng.random((10, 256, 256)) * 255).astype(np.uint8)
+    mhaio.write(tmp_path / "s.mha", vol)
+    x = gc_wrapper.load_image_file_as_array(location=tmp_path / "s.mha")
+    assert x.shape == (1, 10, 256, 256) and x.dtype == torch.float32 and x.is_cuda
+    assert torch.equal(x[0], gc_wrapper.preprocess_sweep(torch.from_numpy(vol).cuda()))
+    torch.manual_seed(0)
+    seg = gc_wrapper.FetalAbdomenSegmentation(base=8)
+    prob = seg.predict([tmp_path / "s.mha"])
+    assert prob.shape == (128, 256, 256) and seg.case_id == "s"
