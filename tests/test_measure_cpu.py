@@ -127,3 +127,23 @@ def test_select_best_takes_the_most_circular_of_the_topk_areas():
 def test_circularity_of_a_disc_is_near_one():
     assert 0.88 < measure.circularity(ellipse_mask(300, 300, 150, 150, 100, 100, 0)) <= 1.0
     assert measure.circularity(ellipse_mask(300, 300, 150, 150, 120, 30, 0)) < 0.6
+
+
+def test_hd95_of_the_evaluation_script():
+    """eval_segmentation_batch.py:51-58 (cross erosion restated; scipy's distance transform as in the reference)."""
+    evalseg = importlib.import_module("att-aspp-unet_amd.evalseg")
+    a = np.zeros((64, 64), np.uint8)
+    b = np.zeros((64, 64), np.uint8)
+    a[20:40, 20:40] = 1
+    assert evalseg.hd95(a, a) == 0.0
+    b[20:40, 23:43] = 255                                   # the same square three pixels to the right
+    assert evalseg.hd95(a, b) == pytest.approx(3.0)
+    c = np.zeros((64, 64), np.uint8)
+    c[15:45, 15:45] = 1                                     # concentric, 5 pixels larger on every side
+    assert 5.0 <= evalseg.hd95(a, c) <= 5 * 2 ** 0.5 + 1e-9
+    assert math.isnan(evalseg.hd95(a, np.zeros_like(a))) and math.isnan(evalseg.hd95(np.zeros_like(a), a))
+    # a mask that touches the image border keeps its rim (cv2 erodes with a +inf border)
+    e = np.zeros((16, 16), np.uint8)
+    e[0:8, 0:8] = 1
+    er = evalseg._erode_cross(e)
+    assert er[0, 0] == 1 and er[7, 7] == 0 and er[0, 7] == 0 and er[3, 3] == 1
