@@ -21,7 +21,8 @@ import torch
 from . import imgproc
 from .model import AttentionASPPUNet
 
-__all__ = ["FetalAbdomenSegmentation", "select_fetal_abdomen_mask_and_frame", "load_image_file_as_array"]
+__all__ = ["FetalAbdomenSegmentation", "select_fetal_abdomen_mask_and_frame", "load_image_file_as_array", "run",
+           "write_array_as_image_file", "convert_2d_mask_to_3d"]
 
 
 def load_image_file_as_array(*, location: Path):
@@ -98,3 +99,60 @@ def select_fetal_abdomen_mask_and_frame(mask_3d):
     if areas[idx] == 0:
         return np.zeros(mask_3d.shape[1:], np.uint8), -1
     return (mask_3d[idx] > 0).astype(np.uint8), idx
+
+
+def convert_2d_mask_to_3d(*, mask_2d, frame_number, number_of_frames):
+    """inference.py:253-269: the 2-D mask (1 -> 2) in frame ``frame_number`` of an empty volume; -1 = no abdomen found."""
+    m = np.where(np.asarray(mask_2d) == 1, 2, 0).astype(np.uint8)
+    vol = np.zeros((number_of_frames,) + m.shape, np.uint8)
+    if frame_number == -1:
+        return vol
+    if frame_number is not None and 0 <= frame_number < number_of_frames:
+        vol[frame_number] = m
+        return vol
+    raise ValueError(f"frame_number must be between -1 and {number_of_frames - 1}, got {frame_number}.")
+
+
+def write_array_as_image_file(*, location, array, frame_number=None, number_of_frames=128, filename="output.mha"):
+    """inference.py:206-251: a compressed uint8 {0, 1} MetaImage volume with 0.28 mm spacing."""
+    from . import mhaio
+    location = Path(location)
+    location.mkdir(parents=True, exist_ok=True)
+    array = np.squeeze(np.asarray(array))
+    if array.ndim != 2:
+        raise ValueError(f"Expected a 2D array, got {array.ndim}D.")
+    vol = convert_2d_mask_to_3d(mask_2d=array.astype(np.float32), frame_number=frame_number, number_of_frames=number_of_frames)
+    vol = np.where(vol > 0.5, 1, 0).astype(np.uint8)
+    mhaio.write(location / filename, vol, like={"ElementSpacing": "0.28 0.28 0.28"}, compress=True)
+
+
+def run(input_path="./test/input", output_path="./test/output", case_id="output", checkpoint_path=None, base=16):
+    """inference.py:50-133, the Grand-Challenge entry point: the sweep under ``<input>/images/stacked-fetal-ultrasound``
+    -> probability maps of 128 sampled frames -> post-processing -> the chosen frame's mask written as
+    ``<output>/images/fetal-abdomen-segmentation/<case_id>.mha`` (a volume with as many frames as the sweep) and
+    ``<output>/fetal-abdomen-frame-number.json``."""
+    import json
+    from glob import glob
+    from . import mhaio
+    input_path, output_path = Path(input_path), Path(output_path)
+    loc = input_path / "images" / "stacked-fetal-ultrasound"
+    files = glob(str(loc / "*.tiff")) + glob(str(loc / "*.mha"))
+    if not files:
+        raise FileNotFoundError(f"no .mha / .tiff sweep under {loc}")
+    algorithm = FetalAbdomenSegmentation(checkpoint_path=checkpoint_path, base=base)
+    prob = algorithm.predict(files, save_probabilities=True)
+    post = algorithm.postprocess(prob)
+    seg, frame = select_fetal_abdomen_mask_and_frame(post)
+    hdr, _ = mhaio.read_header(files[0])
+    dims = [int(t) for t in hdr["DimSize"].split()]
+    ref_w, ref_h, n_frames = dims[0], dims[1], dims[2]
+    if seg.shape != (ref_h, ref_w):            # nearest-neighbour resize to the sweep's frame size (inference.py:96-101)
+        yi = (np.arange(ref_h) * (seg.shape[0] / ref_h)).astype(int).clip(0, seg.shape[0] - 1)
+        xi = (np.arange(ref_w) * (seg.shape[1] / ref_w)).astype(int).clip(0, seg.shape[1] - 1)
+        seg = seg[yi][:, xi]
+    seg = (seg > 0).astype(np.uint8)
+    write_array_as_image_file(location=output_path / "images" / "fetal-abdomen-segmentation", array=seg, frame_number=frame,
+                              number_of_frames=n_frames, filename=f"{case_id}.mha")
+    with open(output_path / "fetal-abdomen-frame-number.json", "w") as f:
+        f.write(json.dumps(int(frame), indent=4))
+    return 0

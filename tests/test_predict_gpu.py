@@ -115,3 +115,34 @@ def test_gc_wrapper_reads_mha(tmp_path):
     seg = gc_wrapper.FetalAbdomenSegmentation(base=8)
     prob = seg.predict([tmp_path / "s.mha"])
     assert prob.shape == (128, 256, 256) and seg.case_id == "s"
+
+
+def test_gc_entry_point_writes_the_challenge_outputs(tmp_path):
+    """inference.py:50-133: <input>/images/stacked-fetal-ultrasound/*.mha -> <output>/images/fetal-abdomen-segmentation/
+    <case>.mha (uint8 {0,1}, one frame set, as many frames as the sweep, 0.28 mm spacing) + the frame-number JSON."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from att_aspp_unet_amd import gc_wrapper, mhaio
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:240, 0:256]
+    vol = np.stack([np.clip(30 + 160 * (((yy - 120) / (30 + k % 40)) ** 2 + ((xx - 128) / (45 + k % 30)) ** 2 < 1) + rng.normal(0, 12, yy.shape),
+                            0, 255).astype(np.uint8) for k in range(140)])
+    loc = tmp_path / "in" / "images" / "stacked-fetal-ultrasound"
+    loc.mkdir(parents=True)
+    mhaio.write(loc / "sweep.mha", vol)
+    torch.manual_seed(0)
+    assert gc_wrapper.run(tmp_path / "in", tmp_path / "out", case_id="caseX", base=8) == 0
+    out, h = mhaio.read(tmp_path / "out" / "images" / "fetal-abdomen-segmentation" / "caseX.mha")
+    frame = json.load(open(tmp_path / "out" / "fetal-abdomen-frame-number.json"))
+    assert out.shape == vol.shape and out.dtype == np.uint8 and set(np.unique(out)) <= {0, 1}
+    assert mhaio.spacing(h) == (0.28, 0.28, 0.28) and h["CompressedData"] == "True"
+    assert -1 <= frame < 128
+    assert all(out[k].max() == 0 for k in range(vol.shape[0]) if k != frame)
+    # the helpers on their own
+    v = gc_wrapper.convert_2d_mask_to_3d(mask_2d=np.eye(4), frame_number=2, number_of_frames=5)
+    assert v.shape == (5, 4, 4) and v[2].max() == 2 and v.sum() == 8
+    assert gc_wrapper.convert_2d_mask_to_3d(mask_2d=np.eye(4), frame_number=-1, number_of_frames=3).sum() == 0
+    with pytest.raises(ValueError):
+        gc_wrapper.convert_2d_mask_to_3d(mask_2d=np.eye(4), frame_number=7, number_of_frames=3)
+    with pytest.raises(FileNotFoundError):
+        gc_wrapper.run(tmp_path / "nothing", tmp_path / "out2")
