@@ -301,8 +301,8 @@ __global__ void normalize_u8_kernel(const unsigned char* src, unsigned char* dst
     dst[i] = sat_u8(__double2int_rn(__dadd_rn(__dmul_rn((double)src[i], scale), shift)));
 }
 
-// CLAHE LUTs: one workgroup per (tile, frame).  The image is padded on the right / bottom to a multiple of the grid
-// with BORDER_REFLECT_101 when it does not divide (clahe.cpp).
+// CLAHE LUTs: one workgroup per (tile, frame).  When either axis does not divide by the grid, clahe.cpp extends BOTH
+// on the right / bottom by tiles - size % tiles with BORDER_REFLECT_101 (tw, th come from the extended size).
 __global__ __launch_bounds__(256) void clahe_lut_kernel(const unsigned char* src, unsigned char* lut, int H, int W, int tw,
                                                         int th, int tiles, float clip_limit) {
     __shared__ int hist[256];
@@ -564,7 +564,10 @@ extern "C" int aau_clahe_u8(const uint8_t* src, uint8_t* dst, uint8_t* lut_ws, i
     IMG_CHECK_DIMS("aau_clahe_u8", N, H, W);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(2, 0, s);
-    const int Wp = (W % tiles) ? W + tiles - W % tiles : W, Hp = (H % tiles) ? H + tiles - H % tiles : H;
+    // clahe.cpp: if EITHER axis does not divide, BOTH grow by tiles - size % tiles (a divisible axis by a whole `tiles`)
+    const bool ext = (W % tiles) || (H % tiles);
+    AAU_REQUIRE(!ext || (W > tiles && H > tiles), "aau_clahe_u8: frame smaller than the tile grid");
+    const int Wp = ext ? W + tiles - W % tiles : W, Hp = ext ? H + tiles - H % tiles : H;
     const int tw = Wp / tiles, th = Hp / tiles;
     hipLaunchKernelGGL(clahe_lut_kernel, dim3(tiles * tiles, N), dim3(256), 0, s, src, lut_ws, H, W, tw, th, tiles, clip_limit);
     hipLaunchKernelGGL(clahe_apply_kernel, IMG_GRID((int64_t)N * H * W), 0, s, src, lut_ws, dst, H, W, tw, th, tiles, N);

@@ -3,10 +3,13 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this package; the product path
 (att-aspp-unet_amd/imgproc.py -> csrc/imgproc.hip) never does.
 
-PARITY UNPINNED against the libraries themselves: the reference calls cv2 (resize, GaussianBlur, CLAHE, medianBlur,
+PINNED: ``median3(clahe(x, 0.8, 8))`` reproduces, with 0 mismatching pixels, the three cv2-written frame pairs the
+reference holds (output/images/frame{000,064,127}_{orig,enh}.png, inference.py:171-183; committed as
+tests/golden/g8_clahe_frames.npz by oracle/make_golden_clahe.py; tests/test_imgproc_oracle_cpu.py).
+PARITY UNPINNED against the libraries themselves for everything else: the reference calls cv2 (resize, GaussianBlur, CLAHE, medianBlur,
 normalize, morphologyEx), skimage.measure.label and scipy.ndimage.binary_fill_holes
 (attention_aspp_unet_pipeline_stage.py:340-348,449-457; model_attention_aspp.py:14-31,66-85).  cv2 and skimage are not
-importable in the build container and the reference ships no fixtures for these steps, so the functions below restate
+importable in the build container and the reference ships no fixtures for the other steps, so the functions below restate
 the PUBLISHED algorithms (OpenCV 4.x imgproc sources: resize.cpp HResizeLinear / VResizeLinear, smooth.dispatch.cpp
 small Gaussian table, clahe.cpp, median_blur, morph; scikit-image label = 8-connected, raster-order numbering).  SciPy IS
 importable: ``scipy.ndimage.label`` / ``binary_fill_holes`` / ``median_filter`` are used directly where the reference
@@ -173,9 +176,14 @@ def clahe(u8, clip_limit=1.0, tiles=8):
     """OpenCV clahe.cpp for 8-bit images."""
     u8 = np.asarray(u8, np.uint8)
     H, W = u8.shape
-    Hp = H + (tiles - H % tiles) % tiles
-    Wp = W + (tiles - W % tiles) % tiles
-    ext = u8[_reflect101(np.arange(Hp), H)][:, _reflect101(np.arange(Wp), W)] if (Hp, Wp) != (H, W) else u8
+    # clahe.cpp (CLAHE_Impl::apply): when EITHER axis does not divide, BOTH are extended by ``tiles - size % tiles``
+    # (copyMakeBorder, BORDER_REFLECT_101) -- a divisible axis grows by a whole ``tiles``: 562x744 -> 568x752, tile 71x94.
+    # Pinned by the frames the reference holds (tests/golden/g8_clahe_frames.npz, 0 mismatching pixels).
+    if H % tiles or W % tiles:
+        Hp, Wp = H + tiles - H % tiles, W + tiles - W % tiles
+        ext = u8[_reflect101(np.arange(Hp), H)][:, _reflect101(np.arange(Wp), W)]
+    else:
+        Hp, Wp, ext = H, W, u8
     th, tw = Hp // tiles, Wp // tiles
     area = th * tw
     climit = 0

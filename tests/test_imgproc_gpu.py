@@ -2,8 +2,11 @@
 numpy / SciPy restatement in oracle/imgproc_ref.py.  Integer and byte work is compared bit for bit; the two fp32
 filters follow the same operation order as the restatement and are compared exactly as well.
 
-Parity against cv2 / skimage themselves is UNPINNED (neither is importable in the build container and the reference
-ships no fixtures for these steps): see the header of oracle/imgproc_ref.py."""
+Parity against cv2 / skimage themselves is UNPINNED (neither is importable in the build container) EXCEPT for CLAHE +
+medianBlur, which the six cv2-written frames the reference holds pin bit for bit (tests/golden/g8_clahe_frames.npz):
+see the header of oracle/imgproc_ref.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -223,3 +226,15 @@ def test_gc_wrapper_end_to_end_shapes_and_alias_module(I):
     assert np.abs(p[k][inside].reshape(224, 224) - 1 / (1 + np.exp(-l))).max() < 2e-2
     mask = seg.postprocess(prob)
     assert mask.shape == prob.shape and mask.dtype == torch.uint8
+
+
+def test_clahe_median_against_the_cv2_frames_the_reference_holds(I):
+    """inference.py:171-183: enh = cv2.medianBlur(cv2.createCLAHE(0.8, (8, 8)).apply(orig), 3) on native 562x744
+    frames, written by real cv2.  The HIP kernels reproduce all three frames with 0 mismatching pixels."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_clahe_frames.npz"))
+    origs = np.stack([g[f"frame{i:03d}_orig"] for i in (0, 64, 127)])
+    enhs = np.stack([g[f"frame{i:03d}_enh"] for i in (0, 64, 127)])
+    out = I.median3(I.clahe(dev(origs), 0.8, 8)).cpu().numpy()                    # batched [3, 562, 744]
+    assert out.shape == enhs.shape and int((out != enhs).sum()) == 0
+    one = I.median3(I.clahe(dev(origs[1]), 0.8, 8)).cpu().numpy()
+    assert np.array_equal(one, enhs[1])

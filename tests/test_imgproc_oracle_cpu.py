@@ -1,5 +1,7 @@
 """The numpy / SciPy restatement of the image steps (oracle/imgproc_ref.py) against independent facts: SciPy's own
 morphology where the border rule coincides, hand-made masks with known answers, filter identities.  No GPU."""
+import os
+
 import numpy as np
 import scipy.ndimage as ndi
 
@@ -79,3 +81,29 @@ def test_gc_crop_and_postprocess_facts():
     prob[2, 5:15, 5:15] = 0.5; prob[2, 30:33, 30:33] = 0.5
     out = R.gc_postprocess(prob)
     assert out[:2].sum() == 0 and out[2, 4:16, 4:16].all() and out[2, 29:34, 29:34].sum() == 0
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_clahe_frames.npz")
+
+
+def test_clahe_median_reproduce_the_frames_the_reference_holds():
+    """inference.py:171-183 wrote frame*_orig / frame*_enh with real cv2: enh = medianBlur(CLAHE(orig), 3).  Native
+    562x744 frames: the height does not divide by 8, so clahe.cpp extends BOTH axes (568x752, tiles 71x94).  The frames
+    were written with clipLimit 0.8 (the value inference.py:168 mentions): bit-exact there, and nowhere else."""
+    g = np.load(GOLD)
+    for i in (0, 64, 127):
+        orig, enh = g[f"frame{i:03d}_orig"], g[f"frame{i:03d}_enh"]
+        assert orig.shape == (562, 744)
+        out = R.median3(R.clahe(orig, 0.8, 8))
+        assert int((out != enh).sum()) == 0
+        assert (R.median3(R.clahe(orig, 1.0, 8)) != enh).mean() > 0.3        # the other documented value is not it
+    sweep = g["clip_sweep"]
+    assert [row[0] for row in sweep if row[1:].sum() == 0] == [0.8]
+
+
+def test_clahe_extends_both_axes_when_one_does_not_divide():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (50, 64)).astype(np.uint8)                      # 64 % 8 == 0, 50 % 8 == 2
+    ext = img[R._reflect101(np.arange(56), 50)][:, R._reflect101(np.arange(72), 64)]
+    # on the extended (divisible) frame no further padding happens: same LUT grid, same interpolation -> same pixels
+    assert np.array_equal(R.clahe(img, 2.0, 8), R.clahe(ext, 2.0, 8)[:50, :64])
