@@ -25,6 +25,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.jo
 EXTRA_FLAGS = {"imgproc.hip": ["-ffp-contract=off"]}
 
 
+def source_hash() -> str:
+    """16 hex digits over every source the library is built from: profiles/*_pmc_traffic.json carry it, and bench.py only
+    quotes a profile's traffic figure when it was measured on THESE kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "aau.h")]):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(src: str, dst: str) -> bool:
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -75,7 +87,9 @@ def build_all(force: bool = False, verbose: bool = True) -> list:
 if __name__ == "__main__":
     defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
     tags = [a[6:] for a in sys.argv[1:] if a.startswith("--tag=")]
-    if not defs and not tags:
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+    elif not defs and not tags:
         print(build_all(force="--force" in sys.argv))
     else:
         print(build(force="--force" in sys.argv, defines=defs, tag=tags[0] if tags else ""))

@@ -93,19 +93,26 @@ class DirectoryLoader:
             x, y = x.flip(-1), y.flip(-1)
         return x, y
 
-    def __iter__(self):
+    def epoch_plan(self):
+        """The epoch's batches as lists of (frame index, flip) -- host logic only, advances the shared generator."""
         n = len(self.imgs)
         if self.train:
+            # every rank draws the SAME permutation and the SAME flips for all n frames (the shared generator stays in
+            # lock-step), keeps (n // world) * world of them and takes its stride: equal shard lengths -> equal batch
+            # counts on every rank (an extra backward on one rank would wait for an all-reduce no peer joins)
             order = torch.randperm(n, generator=self.gen).tolist()
-            order = order[self.rank::self.world] if self.world > 1 else order     # every rank draws the same permutation
-            flips = (torch.rand(len(order), generator=self.gen) < 0.5).tolist()
-            nb = len(order) // self.bs
+            flips = (torch.rand(n, generator=self.gen) < 0.5).tolist()
+            keep = (n // self.world) * self.world
+            order, flips = order[:keep][self.rank::self.world], flips[:keep][self.rank::self.world]
+            nb = (n // self.world) // self.bs
         else:
             order, flips = list(range(n)), [False] * n
             nb = (n + self.bs - 1) // self.bs
-        for b in range(nb):
-            idx = range(b * self.bs, min((b + 1) * self.bs, len(order)))
-            xs, ys = zip(*[self._load(order[k], flips[k]) for k in idx])
+        return [[(order[k], flips[k]) for k in range(b * self.bs, min((b + 1) * self.bs, len(order)))] for b in range(nb)]
+
+    def __iter__(self):
+        for batch in self.epoch_plan():
+            xs, ys = zip(*[self._load(i, f) for i, f in batch])
             yield torch.stack(xs).contiguous(), torch.stack(ys).contiguous()
 
 

@@ -8,8 +8,8 @@ largest 8-connected component.  ``select_fetal_abdomen_mask_and_frame`` is :87-9
 
 The reference file cannot be imported at all (it imports a module ``attention_aspp_unet`` that the repository does not
 contain and constructs the model with keyword names the real class does not have); the alias
-module ``attention_aspp_unet`` at the repository root supplies that name with that signature.  Reading .mha files needs
-SimpleITK, which is not installed here: ``predict`` raises if it is missing, ``predict_array`` takes the array directly.
+module ``attention_aspp_unet`` at the repository root supplies that name with that signature.  ``.mha`` sweeps are read
+by ``mhaio.py`` (no SimpleITK); ``.tiff`` sweeps are refused with a clear error; ``predict_array`` takes the array directly.
 """
 from __future__ import annotations
 
@@ -136,9 +136,11 @@ def run(input_path="./test/input", output_path="./test/output", case_id="output"
     from . import mhaio
     input_path, output_path = Path(input_path), Path(output_path)
     loc = input_path / "images" / "stacked-fetal-ultrasound"
-    files = glob(str(loc / "*.tiff")) + glob(str(loc / "*.mha"))
+    files = sorted(glob(str(loc / "*.mha")))
     if not files:
-        raise FileNotFoundError(f"no .mha / .tiff sweep under {loc}")
+        if glob(str(loc / "*.tiff")):
+            raise NotImplementedError(f"{loc}: .tiff sweeps are not supported (MetaImage .mha only)")
+        raise FileNotFoundError(f"no .mha sweep under {loc}")
     algorithm = FetalAbdomenSegmentation(checkpoint_path=checkpoint_path, base=base)
     prob = algorithm.predict(files, save_probabilities=True)
     post = algorithm.postprocess(prob)

@@ -15,8 +15,10 @@ from typing import Dict, Tuple
 import numpy as np
 
 _TYPES = {"MET_UCHAR": "u1", "MET_CHAR": "i1", "MET_USHORT": "u2", "MET_SHORT": "i2", "MET_UINT": "u4", "MET_INT": "i4",
-          "MET_ULONG": "u8", "MET_LONG": "i8", "MET_FLOAT": "f4", "MET_DOUBLE": "f8"}
-_NAMES = {np.dtype(v).str[1:]: k for k, v in _TYPES.items()}
+          "MET_ULONG": "u4", "MET_LONG": "i4", "MET_ULONG_LONG": "u8", "MET_LONG_LONG": "i8", "MET_FLOAT": "f4",
+          "MET_DOUBLE": "f8"}          # MetaIO's MET_ValueTypeSize: LONG is 4 bytes, LONG_LONG is the 8-byte type
+_NAMES = {"u1": "MET_UCHAR", "i1": "MET_CHAR", "u2": "MET_USHORT", "i2": "MET_SHORT", "u4": "MET_UINT", "i4": "MET_INT",
+          "u8": "MET_ULONG_LONG", "i8": "MET_LONG_LONG", "f4": "MET_FLOAT", "f8": "MET_DOUBLE"}
 
 
 def _truth(v: str) -> bool:

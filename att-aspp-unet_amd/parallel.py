@@ -107,3 +107,16 @@ class DataParallel:
 
     def finish(self):
         self._ensure().finish()
+
+    def sync_buffers(self, src: int = 0):
+        """Broadcast rank ``src``'s module buffers (BatchNorm running mean / var / count): they are updated from each
+        rank's own shard and drift apart; the checkpoint and the validation score are rank 0's."""
+        for b in self.model.buffers():
+            dist.broadcast(b.data, src=src, group=self.group)
+
+    def agree(self, *values: float, src: int = 0):
+        """Rank ``src``'s scalars on every rank (control-flow decisions must be collective)."""
+        dev = next(self.model.parameters()).device
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        dist.broadcast(t, src=src, group=self.group)
+        return tuple(float(v) for v in t.tolist())

@@ -346,8 +346,10 @@ def train(args, train_loader=None, val_loader=None):
     ``python -m torch.distributed.run``), the model is wrapped in ``parallel.DataParallel``: every rank trains on its
     own shard (the synthetic loader is seeded per rank, the directory loader deals the shuffled frames out by rank; a
     caller-supplied loader must shard itself), gradients are
-    all-reduced in buckets under the backward pass, and every rank applies the same update.  Validation runs on every
-    rank over the same set (identical decisions everywhere); rank 0 alone prints and writes checkpoints."""
+    all-reduced in buckets under the backward pass, and every rank applies the same update.  BatchNorm running
+    statistics are per rank, so before validation rank 0's buffers are broadcast and rank 0's Dice / IoU
+    are the ones every rank uses for the best-checkpoint and early-stop decisions -- a rank leaving the epoch loop
+    alone would leave its peers waiting in the next all-reduce.  Rank 0 alone prints and writes checkpoints."""
     import torch.distributed as dist
     from .parallel import DataParallel
     set_seed(args.seed)
@@ -392,7 +394,11 @@ def train(args, train_loader=None, val_loader=None):
             else:
                 opt.step()
             run += loss.detach()
+        if dp is not None:
+            dp.sync_buffers()                    # BatchNorm running statistics diverge per shard: evaluate (and save) rank 0's
         d, i = evaluate(model, val_loader, device)
+        if dp is not None:
+            d, i = dp.agree(d, i)                # one decision for best-checkpoint / early stop on every rank
         history.append((float(run) / max(len(train_loader), 1), d, i))
         if rank == 0:
             print(f"Epoch {ep}/{tot_ep} loss {history[-1][0]:.4f} | Dice {d:.4f} | IoU {i:.4f}")

@@ -39,7 +39,7 @@ def train_gflop_per_image(base_c, size):
 
 
 def host_cores():
-    """CPU share actually available to this process (cgroup quota / affinity), not the host's core count."""
+    """CPU share actually available to this process (cgroup quota / affinity): all of it unless AAU_CPU_THREADS says less."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
@@ -51,12 +51,28 @@ def host_cores():
             n = min(n, max(1, int(int(q) / int(p))))
     except Exception:
         pass
-    return max(1, min(n, int(os.environ.get("AAU_CPU_THREADS", "16"))))
+    if os.environ.get("AAU_CPU_THREADS"):
+        n = min(n, int(os.environ["AAU_CPU_THREADS"]))
+    return max(1, n)
 
 
-def cpu_baseline(base_c, size, batch=8, seconds_budget=40.0):
+def host_cpu_string():
+    """'<model name> x <sockets> sockets, <logical cpus> logical CPUs' from /proc/cpuinfo (the lscpu facts)."""
+    try:
+        model, phys, n = "?", set(), 0
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); n += 1
+            elif line.startswith("physical id"):
+                phys.add(line.split(":", 1)[1].strip())
+        return f"{model}, {max(len(phys), 1)} socket(s), {n} logical CPUs on the host"
+    except Exception:
+        return "unknown"
+
+
+def cpu_baseline(base_c, size, batch=8, seconds_budget=90.0):
     """Time the CPU oracle's train step on a bounded sample of the same workload: the metric's own batch (8), the
-    protocol of BASELINE.md section 3 (2 warm-up + 5 timed steps) when that fits the budget, fewer steps otherwise."""
+    protocol of BASELINE.md section 3 (2 warm-up + 5 timed steps) when that fits ~90 s, fewer timed steps otherwise."""
     from argparse import Namespace
     from oracle import ref_cpu as O
     from att_aspp_unet_amd import synth
@@ -69,13 +85,12 @@ def cpu_baseline(base_c, size, batch=8, seconds_budget=40.0):
     crit = O.build_criterion(Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05), O.ComboLoss(), O.EdgeLoss())
     x, y = synth.make_frames(batch, size, seed=2025)
     t0 = time.perf_counter()
-    O.train_step(net, opt, crit, x, y)                          # warm-up (also sizes the sample)
-    warm = time.perf_counter() - t0
-    n = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
-    nwarm = 1
-    if n == 5 and warm * 7 <= seconds_budget * 1.6:
-        O.train_step(net, opt, crit, x, y)
-        nwarm = 2
+    O.train_step(net, opt, crit, x, y)                          # warm-up 1 (also sizes the sample)
+    t1 = time.perf_counter()
+    O.train_step(net, opt, crit, x, y)                          # warm-up 2
+    warm = time.perf_counter() - t1
+    spent = time.perf_counter() - t0
+    n = max(1, min(5, int((seconds_budget - spent) / max(warm, 1e-3))))
     ts = []
     for _ in range(n):
         t0 = time.perf_counter()
@@ -84,10 +99,39 @@ def cpu_baseline(base_c, size, batch=8, seconds_budget=40.0):
     ts.sort()
     med = ts[len(ts) // 2]
     return {"value": batch / med, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} timed + {nwarm} warm-up fp32 train steps (median) of the CPU oracle at batch {batch}, "
-                      f"{size}x{size}, base_c {base_c}: the metric's own step; BASELINE.md section 3 asks for 2 + 5, "
-                      f"the count is cut to a ~{int(seconds_budget)} s budget",
-            "sec_per_step": med, "sec_per_step_min": ts[0]}
+            "sample": f"{n} timed + 2 warm-up fp32 train steps (median) of the CPU oracle at batch {batch}, "
+                      f"{size}x{size}, base_c {base_c}: the metric's own step (BASELINE.md section 3: 2 + 5, the timed "
+                      f"count cut to a ~{int(seconds_budget)} s budget when a step is slower than that allows)",
+            "host_cpu": host_cpu_string(), "sec_per_step": med, "sec_per_step_min": ts[0]}
+
+
+def library_source_hash():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_aau_build", os.path.join(ROOT, "att-aspp-unet_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
+
+
+def measured_traffic(dom_tag, base_c, size, batch):
+    """HBM bytes per launch of the dominant kernel from the newest profiles/r*_pmc_traffic.json whose ``source_hash``
+    equals the hash of the kernel sources this library was built from (the PMC passes are separate rocprofv3 runs of this
+    very command, scripts/gpu_profile.sh).  A profile of other kernels is stale: -> (None, reason)."""
+    import glob
+    if not (base_c == 48 and size == 512 and batch == 8):
+        return None, "not the profiled configuration"
+    want = library_source_hash()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
+    for f in files:
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if pm.get("source_hash") != want:
+            continue
+        k = pm["by_kernel"].get(dom_tag.split(" ")[0])
+        return (k["bytes_per_launch"], os.path.basename(f)) if k else (None, f"{os.path.basename(f)} has no row for {dom_tag}")
+    return None, f"no profiles/r*_pmc_traffic.json stamped with source hash {want}"
 
 
 def roofline_from_records(recs, nprof, alg_flops, step_s, base_c, size, batch):
@@ -126,17 +170,9 @@ def roofline_from_records(recs, nprof, alg_flops, step_s, base_c, size, batch):
                               round(ms * 1e3, 1), round(tf, 1), round(roof, 1), round(tf / roof, 3)])
     conv_ms = sum(fam.get(k, {"ms": 0.0})["ms"] for k in conv) / nprof
     conv_launches = sum(fam.get(k, {"launches": 0})["launches"] for k in conv) // nprof
-    traffic = None
-    try:   # PMC passes of this very command (separate rocprofv3 runs, corrected as the guide prescribes): profiles/
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            pm = json.load(f)
-        if base_c == 48 and size == 512 and batch == 8:
-            k = pm["by_kernel"].get(dom_tag.split(" ")[0], None)
-            traffic = k["bytes_per_launch"] if k else None
-    except Exception:
-        pass
+    traffic, traffic_src = measured_traffic(dom_tag, base_c, size, batch)
     return {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "frac": dom["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": dom_tag, "dominant_kernel": dict(name=dom_tag, **dom),
             "avg_launch_ms": dom["ms_per_step"] / max(dom["launches_per_step"], 1e-9),
             "alg_bytes_per_launch": dom["alg_gbytes_per_step"] * 1e9 / max(dom["launches_per_step"], 1e-9),
@@ -189,6 +225,50 @@ def inference_numbers(dev):
                                                                                  "frames_per_sec": 1 / t5}}
 
 
+def spawn_ranks(n, argv):
+    """One child process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, as torch.distributed.run
+    sets them); rank 0's stdout is ours.  If a rank dies the others are terminated instead of waiting in a rendezvous
+    nobody will join.  -> exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in live:
+                    q.terminate()
+    return rc
+
+
+def launch_selftest(world, rank):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_selftest": world, "sum_of_rank_plus_one": float(t.item())}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +283,8 @@ def main():
     ap.add_argument("--no-infer", action="store_true", help="skip the inference side numbers (configs 2 and 5)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("AAU_BENCH_GRAPH", "1")),
                     help="replay the step as one hipGraph when possible")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="launcher check without a GPU: the ranks rendezvous over gloo, rank 0 prints one JSON line")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,8 +292,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one fresh process per GPU ourselves.  Nothing in this process has touched
+        # the GPU yet (importing torch does not), and the children are new interpreters, not an exec of this one.
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
+    if a.selftest_launch:
+        return launch_selftest(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)

@@ -40,7 +40,11 @@ def main():
     def canon(k):   # "conv3x3g_kernel<96>" -> "conv3x3g<96>" (the tag bench.py's live profiler reports)
         k = k.replace("_kernel", "").replace(" ", "").replace("false", "0").replace("true", "1")
         return "wgrad3x3<3,8>" if k.startswith("wgrad3x3<3,8") else k
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_aau_build", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "att-aspp-unet_amd", "build.py"))
+    bld = importlib.util.module_from_spec(spec); spec.loader.exec_module(bld)
     res = {
+        "source_hash": bld.source_hash(),     # bench.py quotes these figures only for the kernels they were measured on
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --graph 0; last step",
         "correction": "FETCH_SIZE x 1024 B x 2 (gfx950 counts 128-B read requests as 64 B on wide coalesced streams), WRITE_SIZE x 1024 B",
         "conv_kernels": {"launches_per_step": n_conv, "read_bytes_per_step": conv_rd, "write_bytes_per_step": conv_wr,

@@ -58,3 +58,25 @@ def test_statistics_buffers_are_size_checked_on_the_host():
         with pytest.raises(_abi.AauError, match="stats must be"):
             ops.bn_finalize(bad, *([dummy] * 9), 64, 256.0)
     assert ops.stats_buffer(64, device="cpu").numel() == ops.stat_words(64)
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_several_gpus():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must spawn one fresh process per rank itself:
+    checked without a GPU through the launcher self-test (gloo rendezvous, rank 0 prints the one JSON line)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_selftest": 2, "sum_of_rank_plus_one": 3.0}
+    # a rank that fails takes the whole launch down with its exit code instead of leaving peers in a rendezvous
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs an MI355X" in r.stderr

@@ -40,3 +40,21 @@ def test_split_holds_out_ten_percent_of_the_positives_with_the_reference_rng(tmp
     # no positive frame at all: the candidates are all frames, at least one is held out
     ti, tm, vi, vm = dataset.split_train_val(imgs[:4], [None] * 4, seed=1)
     assert len(vi) == 1 and len(ti) == 3
+
+
+def test_rank_shards_are_disjoint_and_give_every_rank_the_same_number_of_batches(tmp_path):
+    """n = 17 frames, 2 ranks, batches of 3: both ranks must iterate 2 batches (8 // 3), over disjoint frames, and leave
+    the shared generator in the same state (the next epoch's permutation agrees)."""
+    imgs = [tmp_path / f"i{k}.png" for k in range(17)]
+    lds = [dataset.DirectoryLoader(imgs, [None] * 17, 3, 64, True, 2025, "cpu", r, 2) for r in range(2)]
+    for epoch in range(3):
+        plans = [ld.epoch_plan() for ld in lds]
+        assert len(plans[0]) == len(plans[1]) == len(lds[0]) == len(lds[1]) == 2
+        assert all(len(b) == 3 for p in plans for b in p)
+        seen = [{i for b in p for i, _ in b} for p in plans]
+        assert not seen[0] & seen[1]
+    assert lds[0].gen.get_state().equal(lds[1].gen.get_state())
+    one = dataset.DirectoryLoader(imgs, [None] * 17, 3, 64, True, 2025, "cpu")
+    assert len(one.epoch_plan()) == len(one) == 5
+    val = dataset.DirectoryLoader(imgs, [None] * 17, 3, 64, False, 2025, "cpu")
+    assert [len(b) for b in val.epoch_plan()] == [3, 3, 3, 3, 3, 2] and len(val) == 6

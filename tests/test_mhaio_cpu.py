@@ -10,7 +10,7 @@ import pytest
 mhaio = importlib.import_module("att-aspp-unet_amd.mhaio")
 
 
-@pytest.mark.parametrize("dtype", ["uint8", "int16", "uint16", "float32", "float64", "int32"])
+@pytest.mark.parametrize("dtype", ["uint8", "int16", "uint16", "float32", "float64", "int32", "int64", "uint64"])
 @pytest.mark.parametrize("compress", [False, True])
 def test_round_trip(tmp_path, dtype, compress):
     rng = np.random.default_rng(3)
@@ -53,3 +53,17 @@ def test_hand_written_headers(tmp_path):
         mhaio.read(tmp_path / "c.mha")
     with pytest.raises(ValueError):
         mhaio.write(tmp_path / "b.mha", np.zeros((2, 2), dtype=bool))
+
+
+def test_long_types_follow_metaio_sizes(tmp_path):
+    """MET_LONG / MET_ULONG are 4-byte types in MetaIO; the 8-byte ones are MET_LONG_LONG / MET_ULONG_LONG (what ITK
+    writes for int64)."""
+    a = np.arange(24, dtype=np.int64).reshape(2, 3, 4) - 5
+    mhaio.write(tmp_path / "l.mha", a, compress=False)
+    assert mhaio.read_header(tmp_path / "l.mha")[0]["ElementType"] == "MET_LONG_LONG"
+    b, _ = mhaio.read(tmp_path / "l.mha")
+    assert b.dtype == np.int64 and np.array_equal(a, b)
+    v = np.arange(6, dtype="<i4").reshape(2, 3)
+    (tmp_path / "m.mha").write_bytes(b"ObjectType = Image\nNDims = 2\nDimSize = 3 2\nElementType = MET_LONG\nElementDataFile = LOCAL\n" + v.tobytes())
+    c, _ = mhaio.read(tmp_path / "m.mha")
+    assert c.dtype == np.int32 and np.array_equal(c, v)

@@ -150,6 +150,9 @@ def test_trained_step_gradients_match_reference(A, golden):
     assert med < 0.03, (med, p90, worst)
     assert p90 < 0.09, (med, p90, worst)
     assert worst[0] < 0.5, worst
+    # what sits above 10 % must be a near-cancelling sum that carries next to nothing of the gradient (table: < 0.05 %)
+    loud = [r for r in rows if r[0] > 0.10]
+    assert len(loud) <= 8 and all(r[3] < 2e-3 for r in loud), loud
     heavy = [r for r in rows if r[3] >= 1e-3]                # the tensors that carry 99.99 % of the gradient
     assert len(heavy) >= 30 and max(r[1] for r in heavy) < 0.07, sorted(heavy, key=lambda r: -r[1])[:3]
     assert max(r[2] for r in rows) < 5e-3, sorted(rows, key=lambda r: -r[2])[:3]
@@ -297,8 +300,9 @@ def test_benchmark_configuration_step_matches_oracle(A):
     # 1M logits: the maximum is a tail statistic of the bf16 path (3 % at the 65k-pixel fixtures)
     assert stats["logit_max"] < 6e-2 and stats["logit_mean"] < 4e-3, stats
     assert abs(loss_e - float(loss_o)) < 2e-3 * float(loss_o), stats
-    assert cos > 0.97, stats
-    assert abs(float(ge.norm()) - float(gr.norm())) < 0.05 * float(gr.norm()), stats
+    # measured: cosine 0.9999, norm within 0.02 % -- the gates sit one order of magnitude above that
+    assert cos > 0.999, stats
+    assert abs(float(ge.norm()) - float(gr.norm())) < 0.005 * float(gr.norm()), stats
     # running statistics of the first and the last BatchNorm
     sd_e, sd_o = m.state_dict(), ref.state_dict()
     for k in ("d1.0.block.1.running_mean", "d1.0.block.1.running_var", "u1.conv.1.block.1.running_mean",
