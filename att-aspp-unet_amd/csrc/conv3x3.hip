@@ -17,80 +17,9 @@
 // v_mfma_f32_16x16x32_bf16); 66 / 57 KiB LDS -> 2 workgroups per CU.
 #include <stdlib.h>
 #include "common.h"
+#include "c3args.h"
 
 namespace aau {
-
-struct C3Args {
-    aau_conv_desc d;
-    const unsigned short* src;
-    const unsigned short* wpk;
-    unsigned short* dst;
-    const float* bias;
-    const float* scale;
-    const float* shift;
-    float* stats;
-    int rev;             // 1: walk the patches from the end (aau_traverse)
-    int nchunk;          // Cpad / 32
-    unsigned src_bytes, wpk_bytes;
-    int tiles_x, tiles_y;
-    int nowide;          // experiment (AAU_NO_WIDE_STORE): 8-byte epilogue stores
-    int nopair;          // experiment (AAU_RESW_NOPAIR): no two-taps-per-K-block packing of a short last chunk
-};
-
-// 16-B k-group swizzle of the 64-B LDS rows ([row][32 channels]).  ds_read_b128 is serviced in the lane groups
-// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (guide: LDS), i.e. with lane = 16 * kgroup + row a group holds rows
-// f, f+12 of k-group a and rows f+4, f+8 of k-group a^1 for f = 0..3, and the four rows of one residue mod 4 share a
-// 16-bank window: their swizzled k-groups must differ.  kgroup ^ 2*bit2(row) does that for ANY first row (the 3x3
-// taps shift the 16-row window by 0..2 + 18 per halo row); the round-1 form (a 4-entry table on bits 2-3) was
-// conflict-free only for windows that start at a multiple of 8 rows: SQ_LDS_BANK_CONFLICT was 0.22-0.30 of the LDS
-// cycles of every halo kernel.
-__device__ __forceinline__ int swz32(int row, int lc) { return lc ^ ((row >> 1) & 2); }
-
-// epilogue statistics of one accumulator quad (4 consecutive channels q.. of one pixel): (sum v, sum v^2)
-__device__ __forceinline__ void epi_stats(const C3Args&, int64_t, int, const float v[4], float s1[4], float s2[4]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
-}
-
-// Wide epilogue of one pair of accumulator quads (the same 16-channel group of two pixels A, B): statistics, bias and the
-// folded-BN affine in the MFMA layout (channels q .. q+3), then the cross-lane swap of common.h (swap_pair8), after which
-// this lane owns channels qw .. qw+7 of ONE of the two pixels and finishes with a single 16-byte (read-modify-)write at
-// `out`, its own destination for (that pixel, qw).  Every lane of the wave must call this (the swap is a wave operation).
-__device__ __forceinline__ void epi_pair_wide(const C3Args& a, const aau_conv_desc& d, int q, int qw, const f32x4& accA,
-                                              const f32x4& accB, bool want_stats, float s1[4], float s2[4],
-                                              unsigned short* out, bool store) {
-    float va[4], vb[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { va[r] = accA[r]; vb[r] = accB[r]; }
-    if (q < d.Cout) {
-        if (want_stats) { epi_stats(a, 0, q, va, s1, s2); epi_stats(a, 0, q, vb, s1, s2); }
-        if (a.bias) {
-            const f32x4 b = *(const f32x4*)(a.bias + q);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
-        }
-        if (a.scale) {
-            const f32x4 sc = *(const f32x4*)(a.scale + q);
-            const f32x4 sh = *(const f32x4*)(a.shift + q);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
-        }
-    }
-    float w[8];
-    swap_pair8(va, vb, w);
-    if (qw >= d.Cout || !store) return;
-    if (d.accumulate) {
-        float o[8];
-        unpack8(*(const u32x4*)out, o);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) w[r] += o[r];
-    }
-    if (d.relu) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
-    }
-    *(u32x4*)out = pack8(w);
-}
 
 // s_waitcnt takes an immediate; the pipeline below only ever needs these four counts per tile shape
 template <int N>
@@ -2245,6 +2174,10 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     return check_launch("aau_conv_igemm(1x1 resident weights)");
 }
 
+// conv3x3s.hip
+bool conv3x3s_applicable(const aau_conv_desc* d, const void* src, const void* dst);
+int conv3x3s_launch(C3Args& a, hipStream_t s);
+
 // true when conv3x3_launch would take the (single patch stream) resident-weight kernel, the one that serves two-plane
 // operands
 bool conv3x3_split_ok(const aau_conv_desc* d) {
@@ -2278,6 +2211,8 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
     a.nowide = getenv("AAU_NO_WIDE_STORE") != nullptr;
     a.tiles_y = d->H / 16;
     a.nopair = getenv("AAU_RESW_NOPAIR") != nullptr;
+    // 48 / 96 channels in and out: strips with register-resident weights (conv3x3s.hip)
+    if (conv3x3s_applicable(d, src, dst)) return conv3x3s_launch(a, s);
     const bool narrow = d->Cout <= 48;
     const int BQ = narrow ? 48 : 96;
     // resident-weight persistent variant: small weight matrix, many patches, no read-modify-write epilogue

@@ -624,3 +624,71 @@ def test_igemm_group_at_the_real_bridge_shape_and_its_limits(ops):
     assert not ops.conv_igemm_group_ok(bad)
     with pytest.raises(Exception):
         ops.conv_igemm_group(descs, srcs, wpks, out, None)
+
+
+# ---- strips with register-resident weights (conv3x3s.hip): 48 / 96 channels in and out ----
+STRIP_CASES = [
+    # N, H, W, Cin, Cout   (units = N * W/16 * vertical segments; a segment restarts the 16-row block stream)
+    (1, 16, 16, 48, 48),       # one patch: the initial two-row block + one block
+    (2, 48, 32, 96, 48),       # three patches per strip, four units
+    (1, 64, 16, 48, 96),       # one strip cut into vertical segments (two row quads per wave)
+    (3, 32, 80, 96, 96),
+    (2, 256, 16, 48, 48),      # long strips: the ring wraps several times
+    (9, 16, 464, 96, 48),      # more units than CUs (persistent workgroups take a second unit)
+]
+
+
+@pytest.mark.parametrize("case", STRIP_CASES)
+def test_strip_kernel_forward_stats_and_eval_epilogue(ops, case):
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = R.bf16_round(torch.randn(N, H, W, Cin, generator=g))
+    w = R.bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    raw = R.conv_fwd(x, w)
+    cpad = ops.cpad_of(Cin)
+    xd, wd = dev(x.to(torch.bfloat16)), dev(pack_fwd(w, cpad))
+    # training form: raw output + statistics, destination NaN-poisoned (every element must be written exactly once)
+    d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 1, 1, cpad)
+    out = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    stats = ops.stats_buffer(Cout)
+    with launch_tags() as lt:
+        ops.conv_igemm(d, xd, wd, out, stats=stats)
+    assert [t.split(" ")[0] for t in lt] == [f"conv3x3s<{Cin},{Cout}>"], lt
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), raw) < 6e-3
+    s = ops.stats_totals(stats, Cout).float().cpu()
+    flat = raw.reshape(-1, Cout)
+    assert float((s[0] - flat.sum(0)).abs().max()) < 2e-3 * float(flat.abs().sum(0).max())
+    assert torch.allclose(s[1], (flat ** 2).sum(0), rtol=2e-3)
+    # inference form: bias, folded-BN affine, ReLU, padded destination pitch (neighbours untouched)
+    bias, scale, shift = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = torch.relu((raw + bias) * scale + shift)
+    d2 = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout + 8, 3, 3, 1, 1, 1, cpad, relu=1)
+    out2 = torch.zeros(N, H, W, Cout + 8, dtype=torch.bfloat16, device="cuda")
+    ops.conv_igemm(d2, xd, wd, out2, bias=dev(bias), scale=dev(scale), shift=dev(shift))
+    torch.cuda.synchronize()
+    got = out2.cpu()
+    assert rel_err(got[..., :Cout], ref) < 8e-3
+    assert float(got[..., Cout:].abs().max()) == 0
+    # the launch is bitwise reproducible, and identical to the LDS-resident-weight / halo kernels it replaces
+    out3 = torch.empty_like(out)
+    st3 = ops.stats_buffer(Cout)
+    ops.conv_igemm(d, xd, wd, out3, stats=st3)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out3) and torch.equal(stats, st3)
+
+
+def test_strip_kernel_data_gradient_matches_conv2d_input(ops):
+    N, H, W, Cin, Cout = 2, 64, 48, 96, 48          # forward 96 -> 48; its data gradient is a 48 -> 96 convolution
+    g = torch.Generator().manual_seed(11)
+    w = R.bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    dz = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    ref = R.conv_dgrad(dz, w, (H, W))
+    cpd = ops.cpad_of(Cout)
+    dd = ops.conv_desc(N, H, W, Cout, Cout, H, W, Cin, Cin, 3, 3, 1, 1, 1, cpd)
+    din = torch.full((N, H, W, Cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+    with launch_tags() as lt:
+        ops.conv_igemm(dd, dev(dz.to(torch.bfloat16)), dev(pack_dgrad(w, cpd)), din)
+    assert [t.split(" ")[0] for t in lt] == ["conv3x3s<48,96>"], lt
+    torch.cuda.synchronize()
+    assert rel_err(din.cpu(), ref) < 6e-3
