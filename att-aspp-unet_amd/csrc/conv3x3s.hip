@@ -16,6 +16,7 @@
 // block multiplies zero weights) and every LDS address is a row base + an immediate.
 // 12 waves (3 per SIMD, <= 168 VGPRs): wave = (16-channel group g, row-quad slot); one barrier per patch.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "c3args.h"
 
@@ -35,11 +36,42 @@ __device__ __forceinline__ void wait_vm_s() {
     else static_assert(N == 0, "add the immediate");
 }
 
+// Epilogue of one pair of accumulator quads (c3args.h: epi_pair_wide) with the store as a buffer store: statistics, bias,
+// folded-BN affine (staged in LDS as [3][96] floats bias | scale | shift; par = this lane's channel quad in it) in the MFMA layout, the cross-lane swap, ReLU, one
+// 16-byte store at rsD[voff + soff].
+__device__ __forceinline__ void epi_pair_store(const C3Args& a, const aau_conv_desc& d, int q, const f32x4& accA, const f32x4& accB,
+                                               bool want_stats, float s1[4], float s2[4], const unsigned char* par,
+                                               __amdgpu_buffer_rsrc_t rsD, unsigned voff, unsigned soff) {
+    float va[4], vb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { va[r] = accA[r]; vb[r] = accB[r]; }
+    if (want_stats) { epi_stats(a, 0, q, va, s1, s2); epi_stats(a, 0, q, vb, s1, s2); }
+    if (a.bias) {
+        const f32x4 b = *(const f32x4*)(par);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
+    }
+    if (a.scale) {
+        const f32x4 sc = *(const f32x4*)(par + 384);
+        const f32x4 sh = *(const f32x4*)(par + 768);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
+    }
+    float w[8];
+    swap_pair8(va, vb, w);
+    if (d.relu) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(pack8(w), rsD, (int)voff, (int)soff, 0);
+}
+
 // A work unit is a vertical segment of one 16-pixel-wide strip of one image: `segh` patches (the last segment of a strip
 // may be shorter).  The fill stream of a unit is blocks b = -1 .. K-1 of 16 image rows: block b holds rows
 // ys + 16 b + 1 .. ys + 16 b + 16, patch b (rows ys + 16 b ...) needs the last two rows of block b-1 and all of block b.
-template <int CIN, int G>
+template <int CIN, int G, int ABL>
 __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunits, int strips, int nseg, int segh) {
+    constexpr int abl = ABL;                           // timing ablations (AAU_C3S_ABL; builds with -DAAU_C3S_ABLATE only)
     constexpr int PXB = CIN == 48 ? 96 : 224;          // bytes per pixel in LDS
     constexpr int SU = PXB / 16;                       // ... in 16-byte units
     constexpr int NB = CIN == 48 ? 5 : 9;              // K-blocks per vertical tap
@@ -52,9 +84,11 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
     constexpr int NQ = 4 / SLOTS;                      // row quads per wave and patch
     constexpr int NST = NQ * 2;                        // 16-byte stores per lane and patch
     constexpr int BQ = 16 * G;
+    constexpr int PF = CIN == 48 ? 6 : 3;              // pixel fragments in flight per wave
+    static_assert(NF <= NB, "the fills of a block are issued between the K-blocks of one row quad");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(R >= 18 + 16 * D, "ring too small");
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [R][ROWB] ring | 1 KiB scratch
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [R][ROWB] ring | 1 KiB scratch | [3][96] floats
 
     const aau_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -117,30 +151,49 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
     };
     issue_unit_setup();
     int irb = 0;                               // ring row of the next block to issue
-    auto issue_block = [&]() {
+    // one LDS-DMA instruction (1 KiB: a quarter / half of a ring row) of the block under the issue cursor
+    auto issue_one = [&](int i) {
         const bool live = iu < nunits;
-        const int yb = iys + 16 * ib + 1;
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int idx = i * 12 + wave;
-            const int r = idx / IPR;                                   // row of the block (wave-uniform)
-            const int y = yb + r;
-            const bool row_ok = live && idx < 16 * IPR && (unsigned)y < (unsigned)d.H && (ib >= 0 || r >= 14);
-            int rr = irb + r; if (rr >= R) rr -= R;
-            unsigned char* dstp = idx < 16 * IPR ? dsm + rr * ROWB + sub * 1024 : dsm + R * ROWB;
-            const unsigned soff = row_ok ? (unsigned)(((in_ * d.H + y) * d.W) * d.src_pitch * 2) : 0u;
-            const unsigned v = row_ok ? ivec : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, 0);
-        }
+        const int idx = i * 12 + wave;
+        const int r = idx / IPR;                                       // row of the block (wave-uniform)
+        const int y = iys + 16 * ib + 1 + r;
+        const bool row_ok = live && idx < 16 * IPR && (unsigned)y < (unsigned)d.H && (ib >= 0 || r >= 14);
+        int rr = irb + r; if (rr >= R) rr -= R;
+        unsigned char* dstp = idx < 16 * IPR ? dsm + rr * ROWB + sub * 1024 : dsm + R * ROWB;
+        const unsigned soff = row_ok ? (unsigned)(((in_ * d.H + y) * d.W) * d.src_pitch * 2) : 0u;
+        const unsigned v = (row_ok && !(abl & 2)) ? ivec : OOB;       // abl: timing ablations (AAU_C3S_ABL), never set in production
+        if (!(abl & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, 0);
+    };
+    auto issue_end = [&]() {
         irb += 16; if (irb >= R) irb -= R;
-        if (live) {
+        if (iu < nunits) {
             if (++ib == iK) { iu += gridDim.x; ib = -1; issue_unit_setup(); }
         }
     };
+    auto issue_block = [&]() {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) issue_one(i);
+        issue_end();
+    };
 
+    // per-channel epilogue constants of the inference form, staged once (no global loads between the fills and the stores)
+    float* par = (float*)(dsm + R * ROWB + 1024);
+    if (a.bias || a.scale) {
+        for (int i = tid; i < BQ; i += 768) {
+            par[i] = a.bias ? a.bias[i] : 0.f;
+            par[96 + i] = a.scale ? a.scale[i] : 1.f;
+            par[192 + i] = a.scale ? a.shift[i] : 0.f;
+        }
+        __syncthreads();
+    }
+    const unsigned par_off = (unsigned)(R * ROWB + 1024 + (g * 16 + 4 * fk) * 4);
     const bool want_stats = a.stats != nullptr;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const int lane_off = fr * PXB + fk * 16;
+    // after the cross-lane swap of an accumulator pair this lane owns channels qw .. qw+7 of the pixel (row + (fk & 1), fr)
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, 0x7fffffff, 0x00020000);
+    const int qw_ = g * 16 + 8 * (fk >> 1);
+    const unsigned st_voff = (abl & 4) ? 0x80000000u : (unsigned)((((fk & 1) * d.W + fr) * d.dst_pitch + qw_ + (qw_ >= dsplit_c ? dsplit_adj : 0)) * 2);
 
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_block();
@@ -153,10 +206,14 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
         for (int cb = -1; cb < K; ++cb) {
             // block t has landed: the only younger operations are the fills of the blocks behind it and the previous
             // patch's stores (vmcnt retires in issue order)
-            if (prev_patch) wait_vm_s<NF * (D - 1) + NST>(); else wait_vm_s<NF * (D - 1)>();
-            __builtin_amdgcn_s_barrier();
-            issue_block();                      // block t + D, into rows nobody reads any more
+            if (!(abl & 16)) {
+                if (prev_patch) wait_vm_s<NF * (D - 1) + NST>(); else wait_vm_s<NF * (D - 1)>();
+                __builtin_amdgcn_s_barrier();
+            }
+            // block t + D goes into rows nobody reads any more; on a patch step its NF instructions are issued between
+            // the K-blocks of the first row quad instead of in one burst behind the barrier
             prev_patch = cb >= 0;
+            if (cb < 0) issue_block();
             if (cb >= 0) {
                 const int y0 = ys + 16 * cb;
 #pragma unroll
@@ -172,29 +229,39 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
                     f32x4 acc[4];
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-                        constexpr int dummy = 0; (void)dummy;
+                    // pixel fragments in program order s = 6 j + r, read PF ahead of their MFMAs
+                    constexpr int NS = 6 * NB;
+                    auto rd = [&](int s_) -> bf16x8 {
+                        const int j = s_ / 6, r = s_ - 6 * j;
                         const int off = CIN == 48 ? 64 * j : (j / 3) * PXB + (j % 3) * 64;
-                        bf16x8 af[6];
+                        return *(const bf16x8*)(dsm + va[r] + off);
+                    };
+                    bf16x8 af[PF];
 #pragma unroll
-                        for (int r = 0; r < 6; ++r) af[r] = *(const bf16x8*)(dsm + va[r] + off);
+                    for (int s_ = 0; s_ < PF; ++s_) af[s_] = rd(s_);
 #pragma unroll
-                        for (int r = 0; r < 6; ++r)
+                    for (int s_ = 0; s_ < NS; ++s_) {
+                        const int j = s_ / 6, r = s_ - 6 * j;
+                        const bf16x8 cur = (abl & 64) ? wr[0][0] : af[s_ % PF];      // 64: MFMAs without LDS reads
 #pragma unroll
-                            for (int ty = 0; ty < 3; ++ty) {
-                                const int mi = r - ty;
-                                if (mi >= 0 && mi < 4) acc[mi] = AAU_MFMA16(wr[ty][j], af[r], acc[mi], 0, 0, 0);
-                            }
+                        for (int ty = 0; ty < 3; ++ty) {
+                            const int mi = r - ty;
+                            if (mi >= 0 && mi < 4 && !(abl & 1)) acc[mi] = AAU_MFMA16(wr[ty][j], cur, acc[mi], 0, 0, 0);
+                        }
+                        if (s_ + PF < NS) af[s_ % PF] = rd(s_ + PF);
+                        if (qi == 0 && r == 5 && j < NF) issue_one(j);
                     }
-                    // epilogue of the quad: rows in pairs, one 16-byte store per lane and pair (c3args.h)
+                    if (qi == 0) issue_end();
+                    // epilogue of the quad: rows in pairs, one 16-byte buffer store per lane and pair -- the per-lane part
+                    // of the address is a kernel constant, the rest a scalar offset: no 64-bit address registers
+                    if (abl & 8) {                 // ablation: no epilogue (keep the accumulators alive)
+                        if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 1.2345f) s1[0] += 1.f;
+                        continue;
+                    }
 #pragma unroll
                     for (int mp = 0; mp < 4; mp += 2) {
-                        const int yl = y0 + 4 * q + mp + (fk & 1);
-                        const int64_t pl = ((int64_t)n * d.H + yl) * d.W + x0 + fr;
-                        const int qw = g * 16 + 8 * (fk >> 1);
-                        epi_pair_wide(a, d, g * 16 + 4 * fk, qw, acc[mp], acc[mp + 1], want_stats, s1, s2,
-                                      a.dst + pl * d.dst_pitch + qw + (qw >= dsplit_c ? dsplit_adj : 0), true);
+                        const unsigned soff = (unsigned)((((n * d.H + y0 + 4 * q + mp) * d.W) + x0) * d.dst_pitch * 2);
+                        epi_pair_store(a, d, g * 16 + 4 * fk, acc[mp], acc[mp + 1], want_stats, s1, s2, dsm + par_off, rsD, st_voff, soff);
                     }
                 }
             }
@@ -249,20 +316,32 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
     if (nunits > 0x7fffffff) { set_error("conv3x3s: too many units"); return AAU_E_INVALID; }
     const int grid = nunits < 256 ? (int)nunits : 256;
     const bool c48 = d.Cin == 48, g3 = d.Cout == 48;
-    const size_t lds = (c48 ? (size_t)64 * 2048 : (size_t)36 * 4096) + 1024;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)conv3x3s_kernel<48, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)conv3x3s_kernel<48, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)conv3x3s_kernel<96, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)conv3x3s_kernel<96, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    const size_t lds = (c48 ? (size_t)64 * 2048 : (size_t)36 * 4096) + 1024 + 3 * 96 * 4;
+    int abl = 0;
+    if (const char* e = getenv("AAU_C3S_ABL")) abl = atoi(e);       // timing ablations: 1 no MFMA, 2 fills out of range, 4 no stores, 8 no epilogue, 16 no barrier / wait, 32 no fill instructions
     prof_tag(c48 ? (g3 ? "conv3x3s<48,48>" : "conv3x3s<48,96>") : (g3 ? "conv3x3s<96,48>" : "conv3x3s<96,96>"));
-    if (c48 && g3) hipLaunchKernelGGL((conv3x3s_kernel<48, 3>), dim3(grid), dim3(768), lds, s, a, (int)nunits, strips, nseg, segh);
-    else if (c48) hipLaunchKernelGGL((conv3x3s_kernel<48, 6>), dim3(grid), dim3(768), lds, s, a, (int)nunits, strips, nseg, segh);
-    else if (g3) hipLaunchKernelGGL((conv3x3s_kernel<96, 3>), dim3(grid), dim3(768), lds, s, a, (int)nunits, strips, nseg, segh);
-    else hipLaunchKernelGGL((conv3x3s_kernel<96, 6>), dim3(grid), dim3(768), lds, s, a, (int)nunits, strips, nseg, segh);
+    auto go = [&](auto kern) {
+        static bool attr = false;               // one flag per instantiation of this generic lambda
+        if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a, (int)nunits, strips, nseg, segh);
+    };
+    auto pick = [&](auto ablc) {
+        constexpr int A = decltype(ablc)::value;
+        if (c48 && g3) go(conv3x3s_kernel<48, 3, A>);
+        else if (c48) go(conv3x3s_kernel<48, 6, A>);
+        else if (g3) go(conv3x3s_kernel<96, 3, A>);
+        else go(conv3x3s_kernel<96, 6, A>);
+    };
+    switch (abl) {
+#ifdef AAU_C3S_ABLATE
+#define AAU_ABL_CASE(v) case v: pick(std::integral_constant<int, v>{}); break;
+        AAU_ABL_CASE(1) AAU_ABL_CASE(2) AAU_ABL_CASE(4) AAU_ABL_CASE(6) AAU_ABL_CASE(8) AAU_ABL_CASE(14) AAU_ABL_CASE(16)
+        AAU_ABL_CASE(24) AAU_ABL_CASE(32) AAU_ABL_CASE(46) AAU_ABL_CASE(47) AAU_ABL_CASE(63) AAU_ABL_CASE(64) AAU_ABL_CASE(70)
+        AAU_ABL_CASE(78) AAU_ABL_CASE(110) AAU_ABL_CASE(126)
+#undef AAU_ABL_CASE
+#endif
+        default: pick(std::integral_constant<int, 0>{}); break;
+    }
     return check_launch("aau_conv_igemm(3x3 strips, register-resident weights)");
 }
 
