@@ -45,13 +45,18 @@ L = C.c_int64
 F = C.c_float
 U64 = C.c_uint64
 
+# entry points that take an aau_stat buffer: index of the pointer argument; its size in bytes is the NEXT argument
+# (include/aau.h: the library itself refuses an undersized buffer)
+STAT_ARG = {"aau_conv_igemm": 7, "aau_conv1_fwd": 3, "aau_bn_finalize": 0, "aau_gate_psi": 8, "aau_fold_stats": 0,
+            "aau_stats_to_f64": 0}
+
 # name -> argtypes (all return int unless noted)
 _SIGS = {
     "aau_prof_enable": [I],
     "aau_prof_collect": [P, P, P],
     "aau_prof_collect_launches": [I, P, P, P, P, P, P],
     "aau_prof_label": [C.c_char_p],
-    "aau_conv_igemm": [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P],
+    "aau_conv_igemm": [C.POINTER(ConvDesc), P, P, P, P, P, P, P, L, P],
     "aau_conv_is_halo3x3": [C.POINTER(ConvDesc)],
     "aau_traverse": [I],
     "aau_conv_wgrad": [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P],
@@ -62,10 +67,10 @@ _SIGS = {
     "aau_conv_igemm_group_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_igemm_group_ws_bytes": [C.POINTER(ConvDesc), I],
     "aau_conv_igemm_group": [C.POINTER(ConvDesc), P, P, I, P, P, P],
-    "aau_conv1_fwd": [P, P, P, P, I, I, I, I, P],
+    "aau_conv1_fwd": [P, P, P, P, L, I, I, I, I, P],
     "aau_conv1_wgrad": [P, P, P, I, I, I, I, P],
     "aau_pack_weights": [P, P, P, I, L, P],
-    "aau_bn_finalize": [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
+    "aau_bn_finalize": [P, L, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
     "aau_bn_fold_eval": [P, P, P, P, P, P, I, F, P],
     "aau_bn_act": [P, I, P, I, P, P, L, I, I, L, F, P, P],
     "aau_bn_act_pool": [P, I, P, I, P, I, P, P, I, I, I, I, P],
@@ -79,15 +84,15 @@ _SIGS = {
     "aau_gap_fwd": [P, I, P, P, I, I, I, P],
     "aau_gap_bwd": [P, P, I, I, I, I, P],
     "aau_spatial_sum": [P, I, P, P, I, I, I, P],
-    "aau_gate_psi": [P, P, P, P, P, P, P, P, P, L, I, P],
+    "aau_gate_psi": [P, P, P, P, P, P, P, P, P, L, L, I, P],
     "aau_gate_apply": [P, I, P, P, P, P, P, I, L, I, P],
     "aau_gate_bwd1": [P, I, P, I, P, P, P, P, P, I, P, P, L, I, P, P],
     "aau_gate_bwd2": [P] * 21 + [L, I, P, P],
     "aau_gate_bwd3": [P] * 17 + [L, I, P],
     "aau_gate2_fwd": [P, P, P, P, P, I, P, P, I, L, I, I, P],
     "aau_gate2_bwd": [P, I, P, I, P, P, P, P, P, I, P, P, P, P, L, I, I, P],
-    "aau_fold_stats": [P, I, I, I, I, P, P],
-    "aau_stats_to_f64": [P, I, P, P],
+    "aau_fold_stats": [P, L, I, I, I, I, P, P],
+    "aau_stats_to_f64": [P, L, I, P, P],
     "aau_outconv_fwd": [P, I, P, P, P, L, I, P],
     "aau_outconv_bwd": [P, I, P, P, P, I, P, P, P, L, I, P],
     "aau_colsum": [P, I, P, P, L, I, P],

@@ -657,12 +657,13 @@ using namespace aau;
 
 #define CHK_C(fn, C) AAU_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) <= 2048, fn ": C=%d must be a multiple of 8 in [8, 2048]", (int)(C))
 
-extern "C" int aau_bn_finalize(const aau_stat* stats, const float* gamma, const float* beta, float* running_mean,
+extern "C" int aau_bn_finalize(const aau_stat* stats, int64_t stats_bytes, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
                                float* save_mean, float* save_invstd, int C, int64_t count, float eps,
                                float momentum, void* stream) {
     AAU_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd, "aau_bn_finalize: null pointer");
     AAU_REQUIRE(C > 0 && count > 0, "aau_bn_finalize: C=%d count=%lld", C, (long long)count);
+    AAU_CHECK_STAT("aau_bn_finalize", stats, stats_bytes, C);
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, gamma,
                        beta, running_mean, running_var, num_batches_tracked, scale, shift, save_mean, save_invstd, C,

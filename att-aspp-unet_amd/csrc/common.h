@@ -46,7 +46,7 @@ static __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
 // Reduction workspaces are cleared by a kernel, never hipMemsetAsync: a memset node captured into a hipGraph
 // stopped taking effect once the same range had been cleared by an eager hipMemsetAsync (ROCm 7.2, gfx950;
-// scripts/debug_stale.py), which fed garbage partial sums to the replayed forward.
+// round-1 reproduction script), which fed garbage partial sums to the replayed forward.
 static __global__ void zero_f32_kernel(float* __restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0f;
@@ -257,6 +257,12 @@ struct WRedArgs {
 int wg_reduce_launch(int mode, WRedArgs& r, hipStream_t s);
 
 }  // namespace aau
+
+// size / alignment check of an aau_stat buffer handed in through the C ABI (NULL = no statistics wanted)
+#define AAU_CHECK_STAT(fn, stats, bytes, C)                                                                            \
+    AAU_REQUIRE((stats) == nullptr || ((int64_t)(bytes) >= (int64_t)(AAU_STAT_WORDS(C) * 8) && ((uintptr_t)(stats) & 7) == 0), \
+                fn ": statistics buffer of %lld bytes, %lld needed for %d channels (8-byte aligned)", (long long)(bytes),    \
+                (long long)(AAU_STAT_WORDS(C) * 8), (int)(C))
 
 #define AAU_REQUIRE(cond, ...)                      \
     do {                                            \

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void conv3x3g_kernel(const C3Args a) {
 // Every wave issues the same number of LDS-DMA instructions (the spare ones are all-out-of-range pieces that land in
 // a 1-KB scratch area), so the loop has no divergent code and the vmcnt counts are constants.
 // LDS: two halo buffers (42 KB) + 2 slots of 3 tap tiles (36 KB) + scratch = 79 KB -> two workgroups per CU.
-// Where the time goes (scripts/bench_c3fixed.py + the AAU_C3_ABL / AAU_C3_NOSTORE timing ablations, 8 x 256 x 256,
+// Where the time goes (a fixed-shape micro-benchmark + the AAU_C3_ABL / AAU_C3_NOSTORE timing ablations, 8 x 256 x 256,
 // 384 -> 96 channels): the bare read + MFMA + barrier loop runs at 1741 TFLOP/s; the weight LDS-DMA costs 9 %, the
 // halo LDS-DMA 12 %, the output stores 5 %, the statistics epilogue 3-5 %: 1300 as shipped.  ~5 us per workgroup
 // (address tables, first round trip, epilogue) do not shrink with Cin: conv3x3p_kernel below is the persistent form

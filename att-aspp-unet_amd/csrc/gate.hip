@@ -291,8 +291,9 @@ using namespace aau;
 
 extern "C" int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float* sg, const float* hg,
                             const float* sx, const float* hx, const float* wpsi, float* psi_pre, aau_stat* stats,
-                            int64_t M, int F, void* stream) {
+                            int64_t stats_bytes, int64_t M, int F, void* stream) {
     AAU_REQUIRE(zg && zx && sg && hg && sx && hx && wpsi && psi_pre && M > 0, "aau_gate_psi: bad args");
+    AAU_CHECK_STAT("aau_gate_psi", stats, stats_bytes, 1);
     CHK_F("aau_gate_psi", F);
     ProfScope prof(2, 2.0 * M * F, (hipStream_t)stream);
     const CGMap3 mp(F);

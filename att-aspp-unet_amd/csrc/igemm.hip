@@ -667,7 +667,9 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
 
 extern "C" int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
                               aau_bf16* dst, const float* bias, const float* scale, const float* shift,
-                              aau_stat* stats, void* stream) {
+                              aau_stat* stats, int64_t stats_bytes, void* stream) {
+    AAU_REQUIRE(d != nullptr, "aau_conv_igemm: null descriptor");
+    AAU_CHECK_STAT("aau_conv_igemm", stats, stats_bytes, d->Cout);
     return conv_dispatch(d, src, wpk, dst, bias, scale, shift, (float*)stats, stream);
 }
 

@@ -594,11 +594,12 @@ using namespace aau;
 
 #define CHK_C(fn, C) AAU_REQUIRE((C) > 0 && (C) % 8 == 0 && (C) <= 2048, fn ": C=%d must be a multiple of 8 in [8, 2048]", (int)(C))
 
-extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, aau_stat* stats, int N, int H, int W, int C,
+extern "C" int aau_conv1_fwd(const float* x, const float* w, aau_bf16* z, aau_stat* stats, int64_t stats_bytes, int N, int H, int W, int C,
                              void* stream) {
     AAU_REQUIRE(x && w && (z || stats) && N > 0 && H > 0 && W > 0, "aau_conv1_fwd: bad args");
     AAU_REQUIRE((int64_t)N * H * W < 0x7fffffff, "aau_conv1_fwd: pixel count overflows int32");
     CHK_C("aau_conv1_fwd", C);
+    AAU_CHECK_STAT("aau_conv1_fwd", stats, stats_bytes, C);
     const CGMap2 mp(C);
     int64_t blocks, ppb;
     split_rows((int64_t)N * H * W, mp.PL, 16, 4096, &blocks, &ppb);
@@ -720,16 +721,19 @@ __global__ void stats_to_f64_kernel(const long long* stats, int C, double* out) 
     if (i < 2 * C) out[i] = stat_total(stats, C, i / C, i % C);
 }
 
-extern "C" int aau_fold_stats(const aau_stat* stats, int C, int which, int c_begin, int n, float* out, void* stream) {
+extern "C" int aau_fold_stats(const aau_stat* stats, int64_t stats_bytes, int C, int which, int c_begin, int n, float* out,
+                              void* stream) {
     AAU_REQUIRE(stats && out && C > 0 && (which == 0 || which == 1) && c_begin >= 0 && n > 0 && c_begin + n <= C,
                 "aau_fold_stats: bad args");
+    AAU_CHECK_STAT("aau_fold_stats", stats, stats_bytes, C);
     ProfScope prof(2, 0, (hipStream_t)stream);
     hipLaunchKernelGGL(fold_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, C,
                        which, c_begin, n, out);
     return check_launch("aau_fold_stats");
 }
-extern "C" int aau_stats_to_f64(const aau_stat* stats, int C, double* out, void* stream) {
+extern "C" int aau_stats_to_f64(const aau_stat* stats, int64_t stats_bytes, int C, double* out, void* stream) {
     AAU_REQUIRE(stats && out && C > 0, "aau_stats_to_f64: bad args");
+    AAU_CHECK_STAT("aau_stats_to_f64", stats, stats_bytes, C);
     hipLaunchKernelGGL(stats_to_f64_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)stats, C, out);
     return check_launch("aau_stats_to_f64");

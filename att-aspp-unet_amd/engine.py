@@ -78,6 +78,10 @@ class _Rec:
                 conv.append(C.byref(a))
             else:
                 conv.append(a)
+        si = _abi.STAT_ARG.get(name)
+        if si is not None:      # aau_stat pointer: its size in bytes follows it (the library checks it against the channel count)
+            t = args[si]
+            conv.insert(si + 1, 0 if t is None else t.numel() * t.element_size())
         self.ops.append((f, tuple(conv), name, 1 if side else 0, self.label))
         self.uses_side |= side
 
@@ -530,7 +534,7 @@ class Plan:
         # Concat buffers torch.cat([skip, up], 1) (pipeline:108).  Interleaved [M][2C] by default; an ungated level whose
         # consumer kernels take two-plane operands (aau.h, aau_conv_split_ok) keeps TWO DENSE PLANES [2][M][C] instead:
         # at C = 48 the 96-byte half rows at a 192-byte pitch cost their writers 2x and their readers 1.5x per byte
-        # (scripts/bench_pitch.py) -- the encoder output, the transposed conv and their gradients at level 1.
+        # (round-2 micro-benchmark) -- the encoder output, the transposed conv and their gradients at level 1.
         planar = [self._planar_ok(lv, gate_kinds[lv], B, Hs[lv], Ws[lv], Cs[lv], tr) for lv in range(4)]
         cats = [self.new(2, Ms[lv], Cs[lv]) if planar[lv] else self.new(Ms[lv], 2 * Cs[lv]) for lv in range(4)]
         cat_p = [Cs[lv] if planar[lv] else 2 * Cs[lv] for lv in range(4)]            # pixel pitch of either half

@@ -44,6 +44,11 @@ def stats_buffer(C: int, device="cuda") -> torch.Tensor:
     return torch.zeros(stat_words(C), dtype=torch.int64, device=device)
 
 
+def _nb(t) -> int:
+    """Size in bytes of a tensor handed to the C ABI (0 for None)."""
+    return 0 if t is None else t.numel() * t.element_size()
+
+
 def _check_stats(stats, C: int, what: str):
     """The kernels add into [R][2][C] two-limb int64 slots + a poison word: a buffer sized for anything else (e.g. the
     fp32 [R][2][C] of round 1) would be written out of bounds, so the size is checked on the host."""
@@ -57,13 +62,13 @@ def _check_stats(stats, C: int, what: str):
 def stats_totals(stats: torch.Tensor, C: int) -> torch.Tensor:
     """fp64 [2, C]: (sum, sum of squares) per channel of an aau_stat buffer."""
     out = torch.empty(2, C, dtype=torch.float64, device=stats.device)
-    check(fn("aau_stats_to_f64")(_p(stats), C, _p(out), _stream()), "aau_stats_to_f64")
+    check(fn("aau_stats_to_f64")(_p(stats), _nb(stats), C, _p(out), _stream()), "aau_stats_to_f64")
     return out
 
 
 def fold_stats(stats, C, which, c_begin, n, out):
     _check_stats(stats, C, "fold_stats")
-    check(fn("aau_fold_stats")(_p(stats), C, which, c_begin, n, _p(out), _stream()), "aau_fold_stats")
+    check(fn("aau_fold_stats")(_p(stats), _nb(stats), C, which, c_begin, n, _p(out), _stream()), "aau_fold_stats")
 
 
 def pitch_of(t: torch.Tensor) -> int:
@@ -99,7 +104,7 @@ def conv_split_ok(desc: ConvDesc, mode: int) -> bool:
 def conv_igemm(desc: ConvDesc, src, wpk, dst, bias=None, scale=None, shift=None, stats=None):
     _check_stats(stats, desc.Cout, "conv_igemm")
     check(fn("aau_conv_igemm")(C.byref(desc), _p(src), _p(wpk), _p(dst), _p(bias), _p(scale), _p(shift),
-                               _p(stats), _stream()), "aau_conv_igemm")
+                               _p(stats), _nb(stats), _stream()), "aau_conv_igemm")
 
 
 def conv_is_halo3x3(desc: ConvDesc) -> bool:
@@ -169,7 +174,7 @@ def conv_igemm_group(descs, srcs, wpks, dst, ws=None):
 
 def conv1_fwd(x, w, z, stats, N, H, W, Cc):
     _check_stats(stats, Cc, "conv1_fwd")
-    check(fn("aau_conv1_fwd")(_p(x), _p(w), _p(z), _p(stats), N, H, W, Cc, _stream()), "aau_conv1_fwd")
+    check(fn("aau_conv1_fwd")(_p(x), _p(w), _p(z), _p(stats), _nb(stats), N, H, W, Cc, _stream()), "aau_conv1_fwd")
 
 
 def conv1_wgrad(x, dz, dw, N, H, W, Cc):
@@ -184,7 +189,7 @@ def pack_weights(flat, packed, table_dev, n_entries, total_blocks):
 def bn_finalize(stats, gamma, beta, rmean, rvar, nbt, scale, shift, smean, sinvstd, Cc, count,
                 eps=1e-5, momentum=0.1):
     _check_stats(stats, Cc, "bn_finalize")
-    check(fn("aau_bn_finalize")(_p(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(scale),
+    check(fn("aau_bn_finalize")(_p(stats), _nb(stats), _p(gamma), _p(beta), _p(rmean), _p(rvar), _p(nbt), _p(scale),
                                 _p(shift), _p(smean), _p(sinvstd), Cc, count, eps, momentum, _stream()),
           "aau_bn_finalize")
 
@@ -295,7 +300,7 @@ def spatial_sum(src, sp, out, ws, N, HW, Cc):
 def gate_psi(zg, zx, sg, hg, sx, hx, wpsi, psi_pre, stats, M, Fi):
     _check_stats(stats, 1, "gate_psi")
     check(fn("aau_gate_psi")(_p(zg), _p(zx), _p(sg), _p(hg), _p(sx), _p(hx), _p(wpsi), _p(psi_pre),
-                             _p(stats), M, Fi, _stream()), "aau_gate_psi")
+                             _p(stats), _nb(stats), M, Fi, _stream()), "aau_gate_psi")
 
 
 def gate_apply(x, xp, psi_pre, scale1, shift1, alpha, out, op, M, Cc):

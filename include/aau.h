@@ -44,6 +44,9 @@ typedef uint16_t aau_bf16;
 /* [AAU_STAT_REPLICAS][2][C][2 limbs] followed by one poison word (+1 pad); value = hi*2^-8 + lo*2^-52, added  */
 /* with 64-bit integer atomics, so the totals are the same bits for every arrival order (BatchNorm batch      */
 /* statistics no longer differ from run to run).  The caller zeroes the buffer (AAU_STAT_WORDS(C) words).     */
+/* Every entry point that takes an aau_stat buffer also takes its size in BYTES right behind the pointer and    */
+/* refuses a buffer smaller than AAU_STAT_WORDS(C) * 8 for the channel count of the call: the epilogues' 64-bit */
+/* atomics reach up to the poison word, so an undersized buffer would be an out-of-bounds device write.         */
 typedef int64_t aau_stat;
 #define AAU_STAT_WORDS(C) ((size_t)AAU_STAT_REPLICAS * 2 * (size_t)(C) * 2 + 2)
 
@@ -94,7 +97,7 @@ typedef struct aau_conv_desc {
     /* dense plane, element offset split_off from the base, same pixel pitch.  0 = one plane.   */
     /* torch.cat([skip, up], 1) of the decoder (pipeline:108) at level 1 is kept as two dense   */
     /* [M][Co] planes: 96-byte half rows at a 192-byte pitch cost 1.5-2x per byte on gfx950      */
-    /* (scripts/bench_pitch.py).  Only the kernels aau_conv_split_ok() names take them.          */
+    /* (round-2 micro-benchmark).  Only the kernels aau_conv_split_ok() names take them.          */
     int32_t src_split_c, src_split_off;
     int32_t dst_split_c, dst_split_off;
 } aau_conv_desc;
@@ -109,7 +112,7 @@ typedef struct aau_conv_desc {
 /* aau_bn_finalize / aau_fold_stats).  The caller zeroes stats beforehand.                */
 int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk,
                    aau_bf16* dst, const float* bias, const float* scale, const float* shift,
-                   aau_stat* stats, void* stream);
+                   aau_stat* stats, int64_t stats_bytes, void* stream);
 
 /* 1 when the launch this descriptor selects supports its two-plane operands (src_split_c /  */
 /* dst_split_c): mode 0 = aau_conv_igemm (the resident-weight 3x3 kernels), 1 = aau_conv_wgrad */
@@ -171,7 +174,7 @@ int aau_conv_igemm_group(const aau_conv_desc* descs, const aau_bf16* const* srcs
 int aau_traverse(int alternate);
 
 /* ---- first layer: Conv2d(1, C, 3, pad 1) on fp32 input (pipeline:113 d1[0]) --------- */
-int aau_conv1_fwd(const float* x, const float* w /*[C][9]*/, aau_bf16* z, aau_stat* stats,
+int aau_conv1_fwd(const float* x, const float* w /*[C][9]*/, aau_bf16* z, aau_stat* stats, int64_t stats_bytes,
                   int N, int H, int W, int C, void* stream);
 int aau_conv1_wgrad(const float* x, const aau_bf16* dz, float* dw /*[C][9]*/,
                     int N, int H, int W, int C, void* stream);
@@ -197,7 +200,7 @@ int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_pack_entry* 
 /* ---- BatchNorm2d (pipeline:64 and every BN of :71-90) -------------------------------- */
 /* training: stats replicas -> mean / biased var -> scale = g*invstd, shift = b-mean*scale; */
 /* saves mean, invstd; running stats: momentum 0.1, unbiased var; nbt += 1.              */
-int aau_bn_finalize(const aau_stat* stats, const float* gamma, const float* beta,
+int aau_bn_finalize(const aau_stat* stats, int64_t stats_bytes, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* scale, float* shift, float* save_mean, float* save_invstd,
                     int C, int64_t count, float eps, float momentum, void* stream);
@@ -289,7 +292,7 @@ int aau_spatial_sum(const aau_bf16* src, int src_pitch, aau_bf16* out, float* ws
 /* sumsq of psi_pre into stats [REPLICAS][2][1].                                           */
 int aau_gate_psi(const aau_bf16* zg, const aau_bf16* zx, const float* sg, const float* hg,
                  const float* sx, const float* hx, const float* wpsi, float* psi_pre,
-                 aau_stat* stats, int64_t M, int F, void* stream);
+                 aau_stat* stats, int64_t stats_bytes, int64_t M, int F, void* stream);
 /* alpha[m] = sigmoid(psi_pre*scale1+shift1); out[m,c] = x[m,c]*alpha[m]                   */
 int aau_gate_apply(const aau_bf16* x, int x_pitch, const float* psi_pre, const float* scale1,
                    const float* shift1, float* alpha, aau_bf16* out, int out_pitch, int64_t M,
@@ -356,9 +359,9 @@ int aau_colsum(const aau_bf16* src, int src_pitch, float* out, float* ws, int64_
 int aau_fold_replicas(const float* ws, int stride, float* out, int n, void* stream);
 /* out[i] += total of statistic `which` (0 sum, 1 sum of squares) of channel c_begin + i of an aau_stat buffer   */
 /* for C channels (e.g. the ConvTranspose2d bias gradient = channel sums that a data-gradient conv accumulated) */
-int aau_fold_stats(const aau_stat* stats, int C, int which, int c_begin, int n, float* out, void* stream);
+int aau_fold_stats(const aau_stat* stats, int64_t stats_bytes, int C, int which, int c_begin, int n, float* out, void* stream);
 /* out fp64 [2][C] = the totals of an aau_stat buffer (NaN if poisoned by a non-finite partial)                   */
-int aau_stats_to_f64(const aau_stat* stats, int C, double* out, void* stream);
+int aau_stats_to_f64(const aau_stat* stats, int64_t stats_bytes, int C, double* out, void* stream);
 
 /* Residual gate of the ablation variant (test_ablation.py:128-143; no BatchNorm, bias on psi):     */
 /*   alpha[m] = sigmoid(sum_f wpsi[f]*relu(zg[m,f]+zx[m,f]) + bpsi);  out[m,c] = x[m,c]*alpha[m] + x[m,c] */
