@@ -113,6 +113,13 @@ _SIGS = {
     "aau_morph": [P, P, I, I, I, I, I, P],
     "aau_normalize_minmax_u8": [P, P, P, I, I, I, P],
     "aau_clahe_u8": [P, P, P, I, I, I, F, I, P],
+    "aau_hflip_frames_u8": [P, P, P, I, I, I, P],
+    "aau_warp_affine_u8": [P, P, P, I, I, I, I, I, P],
+    "aau_lut_u8": [P, P, P, I, L, P],
+    "aau_elastic_noise": [P, P, I, I, I, P],
+    "aau_gauss_sep_f32": [P, P, P, P, I, L, I, I, P],
+    "aau_remap_u8": [P, P, P, P, I, I, I, I, P],
+    "aau_select_frames_u8": [P, P, P, P, I, L, P],
     "aau_median3_u8": [P, P, I, I, I, P],
     "aau_u8_to_f32": [P, P, F, L, P],
     "aau_roi_origin": [P, P, P, I, I, I, I, P],

@@ -15,14 +15,14 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libaau.so")
-SOURCES = ["runtime.hip", "igemm.hip", "igemm_group.hip", "conv3x3.hip", "conv3x3s.hip", "wgrad.hip", "wgrad3x3.hip", "wgradL.hip", "wgrad3x3r.hip", "bn.hip", "pointwise.hip", "gate.hip", "loss.hip", "optim.hip", "imgproc.hip"]
+SOURCES = ["runtime.hip", "igemm.hip", "igemm_group.hip", "conv3x3.hip", "conv3x3s.hip", "wgrad.hip", "wgrad3x3.hip", "wgradL.hip", "wgrad3x3r.hip", "bn.hip", "pointwise.hip", "gate.hip", "loss.hip", "optim.hip", "imgproc.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wno-unused-result", "-Wno-unused-value"]
 
 
 # per-file flags: the image kernels restate published algorithms operation by operation (separately rounded multiplies
 # and adds), so hipcc's default fused-multiply-add contraction is off for that file
-EXTRA_FLAGS = {"imgproc.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"imgproc.hip": ["-ffp-contract=off"], "augment.hip": ["-ffp-contract=off"]}
 
 
 def source_hash() -> str:

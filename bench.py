@@ -269,6 +269,38 @@ def launch_selftest(world, rank):
     dist.destroy_process_group()
 
 
+def loader_numbers(dev, n=96):
+    """Feed rate of the input pipeline (not the metric): n synthetic 562x744 PNG frames + masks on
+    local disk -> DirectoryLoader (thread-pool decode, GPU Resize + the random augmentations of pipeline:149-153) -> batches
+    of 8 x 1x512x512, one warm-up epoch and one timed epoch."""
+    import tempfile
+    import numpy as np
+    from pathlib import Path
+    from PIL import Image
+    from att_aspp_unet_amd import dataset, synth
+    with tempfile.TemporaryDirectory() as td:
+        root = Path(td)
+        (root / "images").mkdir(); (root / "masks").mkdir()
+        x, y = synth.make_frames(8, 512, seed=3)
+        for k in range(n):
+            fr = (np.pad(x[k % 8, 0].numpy(), ((25, 25), (116, 116))) * 255).astype(np.uint8)     # 562 x 744, the native size
+            Image.fromarray(np.roll(fr, 3 * k, axis=1)).save(root / "images" / f"c{k:03d}.png")
+            if k % 5:
+                Image.fromarray((np.pad(y[k % 8, 0].numpy(), ((25, 25), (116, 116))) * 255).astype(np.uint8)).save(root / "masks" / f"c{k:03d}.png")
+        imgs, msks = dataset.collect_pair(root / "images", root / "masks")
+        out = {}
+        for workers in (1, host_cores()):
+            ld = dataset.DirectoryLoader(imgs, msks, 8, 512, train=True, seed=2025, device=dev, workers=workers)
+            list(ld)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cnt = sum(b[0].shape[0] for b in ld)
+            torch.cuda.synchronize()
+            out[f"frames_per_sec_{workers}_decode_threads"] = cnt / (time.perf_counter() - t0)
+        out["what"] = f"{n} PNG frames 562x744 (+ masks) from local disk -> augmented 8 x 1x512x512 device batches"
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,6 +443,12 @@ def main():
             infer = inference_numbers(dev)
         except Exception as e:   # reported, never fatal for the metric line
             infer = {"error": f"{type(e).__name__}: {e}"}
+    loader = None
+    if rank == 0 and world == 1 and not a.no_roofline and not a.no_infer:
+        try:
+            loader = loader_numbers(dev)
+        except Exception as e:   # reported, never fatal for the metric line
+            loader = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.base_c, a.size, a.batch)
@@ -427,7 +465,7 @@ def main():
                                    f"fp32 master weights" + (", RCCL grad all-reduce overlapped with backward" if world > 1 else ""),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
                        "final_loss": loss_val, "images_per_sec_with_h2d_of_inputs": h2d,
-                       "inference_not_the_metric": infer},
+                       "inference_not_the_metric": infer, "input_pipeline_not_the_metric": loader},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

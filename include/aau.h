@@ -482,6 +482,30 @@ int aau_roi_paste_sigmoid(const float* logits, const int32_t* origin, float* ful
 /* :66-69: areas[f] = #(prob > thr)                                                                                */
 int aau_frame_areas(const float* prob, float thr, int32_t* areas, int N, int H, int W, void* stream);
 
+/* ---- random training augmentations of FetalACDataset (pipeline:149-153), batched over resident uint8 frames ------ */
+/* Every entry takes PER-FRAME parameters; a frame whose transform was not drawn gets the identity (matrix / table /  */
+/* alpha 0 / flag 0), so one launch serves a batch.  albumentations / cv2 published algorithms with exact bilinear    */
+/* weights (parity unpinned: neither library is importable in the build container).                                 */
+/* HorizontalFlip(0.5) (pipeline:149): frames whose flag is set are mirrored along x                                 */
+int aau_hflip_frames_u8(const uint8_t* src, uint8_t* dst, const uint8_t* flags, int N, int H, int W, void* stream);
+/* Affine(scale, rotate, translate_percent, p=0.7) (pipeline:150) = cv2.warpAffine: dst(x,y) = src(M (x,y,1)); inv_mats */
+/* fp64 [N][6] = the dst->src maps; bilinear (image) or nearest (mask), constant `border` outside the frame          */
+int aau_warp_affine_u8(const uint8_t* src, uint8_t* dst, const double* inv_mats, int N, int H, int W, int nearest,
+                       int border, void* stream);
+/* RandomGamma / RandomBrightnessContrast (pipeline:151-152) = cv2.LUT with one 256-entry table per frame            */
+int aau_lut_u8(const uint8_t* src, uint8_t* dst, const uint8_t* luts /*[N][256]*/, int N, int64_t HW, void* stream);
+/* ElasticTransform(alpha, sigma) (pipeline:153): out fp32 [N][2][H][W] uniform noise in [-1, 1), counter based        */
+/* (keyed by seeds[n], plane, pixel); then aau_gauss_sep_f32 (GaussianBlur, BORDER_REFLECT_101, `ksize` taps, tmp of  */
+/* the same size) and aau_remap_u8: dst(x,y) = src(x + alpha[n] dx, y + alpha[n] dy), BORDER_REFLECT_101              */
+int aau_elastic_noise(const uint64_t* seeds, float* out, int N, int H, int W, void* stream);
+int aau_gauss_sep_f32(const float* src, float* dst, float* tmp, const float* taps, int ksize, int64_t planes, int H,
+                      int W, void* stream);
+int aau_remap_u8(const uint8_t* src, uint8_t* dst, const float* disp, const float* alpha, int N, int H, int W,
+                 int nearest, void* stream);
+/* CLAHE / MedianBlur are drawn per frame (albumentations' default p = 0.5, pipeline:153,155): out[n] = flags[n] ? a : b */
+int aau_select_frames_u8(const uint8_t* a, const uint8_t* b, const uint8_t* flags, uint8_t* out, int N, int64_t HW,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
 """``train --train_dir`` end to end (reference pipeline:244-333 with FetalACDataset :143-170): PNG files in images/ and
-masks/, decoded by PIL, Resize -> CLAHE -> MedianBlur -> ToFloat on the GPU, one short epoch."""
+masks/, decoded by a thread pool (PIL), Resize -> random augmentations -> CLAHE -> MedianBlur -> ToFloat on the GPU, one
+short epoch.  The transform itself is checked against the numpy restatement in tests/test_augment_gpu.py."""
 import types
 
 import numpy as np
@@ -31,7 +32,7 @@ def test_directory_loader_matches_the_validation_transform_and_shards(tmp_path):
     from att_aspp_unet_amd import dataset, imgproc
     _write_set(tmp_path / "d", 10, np.random.default_rng(0))
     imgs, msks = dataset.collect_pair(tmp_path / "d" / "images", tmp_path / "d" / "masks")
-    val = dataset.DirectoryLoader(imgs, msks, 4, 64, train=False, device="cuda")
+    val = dataset.DirectoryLoader(imgs, msks, 4, 64, train=False, device="cuda", augment=False)
     batches = list(val)
     assert [b[0].shape[0] for b in batches] == [4, 4, 2] and len(val) == 3
     x0, y0 = batches[0]
@@ -44,7 +45,7 @@ def test_directory_loader_matches_the_validation_transform_and_shards(tmp_path):
     a = dataset.DirectoryLoader(imgs, msks, 2, 64, train=True, seed=3, device="cuda", rank=0, world=2)
     b = dataset.DirectoryLoader(imgs, msks, 2, 64, train=True, seed=3, device="cuda", rank=1, world=2)
     assert len(a) == 2 and len(list(a)) == 2 and len(list(b)) == 2
-    one = dataset.DirectoryLoader(imgs, msks, 5, 64, train=True, seed=3, device="cuda")
+    one = dataset.DirectoryLoader(imgs, msks, 5, 64, train=True, seed=3, device="cuda", augment=False)
     e1 = torch.cat([x for x, _ in one])
     e2 = torch.cat([x for x, _ in one])
     assert e1.shape[0] == 10 and not torch.equal(e1, e2)      # reshuffled
@@ -54,6 +55,20 @@ def test_directory_loader_matches_the_validation_transform_and_shards(tmp_path):
         assert any(torch.equal(x, r) or torch.equal(x, r.flip(-1)) for r in ref.values())
     with pytest.raises(ValueError):
         dataset.DirectoryLoader(imgs, msks, 16, 64, train=True, device="cuda")
+    # the reference's validation transform draws CLAHE and MedianBlur with p = 0.5 each (albumentations' default): every
+    # frame is one of the four combinations of the two, and the draw is a function of (seed, epoch, frame) only
+    from att_aspp_unet_amd import augment
+    rv = dataset.DirectoryLoader(imgs, msks, 4, 64, train=False, seed=11, device="cuda")
+    xs = torch.cat([x for x, _ in rv])
+    prm = augment.sample(list(range(10)), 64, 64, 11, 0, train=False)
+    for i, pth in enumerate(imgs):
+        r = imgproc.resize_bilinear(torch.from_numpy(np.array(Image.open(pth).convert("L"))).cuda()[None], (64, 64))
+        if prm.clahe[i]:
+            r = imgproc.clahe(r)
+        if prm.median[i]:
+            r = imgproc.median3(r)
+        assert torch.equal(xs[i, 0], imgproc.to_float(r)[0]), i
+    assert 0 < prm.clahe.sum() + prm.median.sum() < 20
 
 
 def test_train_from_a_directory(tmp_path, capsys):
