@@ -69,25 +69,30 @@ __device__ __forceinline__ void epi_pair_store(const C3Args& a, const aau_conv_d
 // A work unit is a vertical segment of one 16-pixel-wide strip of one image: `segh` patches (the last segment of a strip
 // may be shorter).  The fill stream of a unit is blocks b = -1 .. K-1 of 16 image rows: block b holds rows
 // ys + 16 b + 1 .. ys + 16 b + 16, patch b (rows ys + 16 b ...) needs the last two rows of block b-1 and all of block b.
-template <int CIN, int G, int ABL>
-__global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunits, int strips, int nseg, int segh) {
+// NWV waves per workgroup and PR patch rows: (12, 16) = one workgroup per CU, (6, 8) = TWO independent workgroups per CU
+// (half the ring each): while one of them sits in its barrier / epilogue / first-fragment latency the other one keeps the
+// matrix pipes busy -- with one workgroup per CU all twelve waves go through those phases together.
+template <int CIN, int G, int NWV, int PR, int ABL, bool STAG>
+__global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, int nunits, int strips, int nseg, int segh) {
     constexpr int abl = ABL;                           // timing ablations (AAU_C3S_ABL; builds with -DAAU_C3S_ABLATE only)
     constexpr int PXB = CIN == 48 ? 96 : 224;          // bytes per pixel in LDS
     constexpr int SU = PXB / 16;                       // ... in 16-byte units
     constexpr int NB = CIN == 48 ? 5 : 9;              // K-blocks per vertical tap
     constexpr int ROWB = CIN == 48 ? 2048 : 4096;      // bytes per ring row (18 px, padded to whole 1-KiB DMA pieces)
     constexpr int IPR = ROWB / 1024;                   // LDS-DMA instructions per row
-    constexpr int R = CIN == 48 ? 64 : 36;             // ring rows
     constexpr int D = CIN == 48 ? 2 : 1;               // blocks in flight
-    constexpr int NF = (16 * IPR + 11) / 12;           // fill instructions per wave and block
-    constexpr int SLOTS = 12 / G;                      // row-quad slots
-    constexpr int NQ = 4 / SLOTS;                      // row quads per wave and patch
+    constexpr int R = PR == 16 ? (CIN == 48 ? 64 : 36) : (CIN == 48 ? 26 : 18);   // ring rows
+    constexpr int FW = NWV / IPR * IPR;                // waves that issue fills (a lane's piece of a row must not depend on i)
+    constexpr int NF = (PR * IPR + FW - 1) / FW;       // fill instructions per wave and block
+    constexpr int SLOTS = NWV / G;                     // row-quad slots
+    constexpr int NQ = (PR / 4) / SLOTS;               // row quads per wave and patch
+    static_assert(SLOTS >= 1 && NQ >= 1 && NQ * SLOTS * 4 == PR, "waves x quads must tile the patch");
     constexpr int NST = NQ * 2;                        // 16-byte stores per lane and patch
     constexpr int BQ = 16 * G;
     constexpr int PF = CIN == 48 ? 6 : 3;              // pixel fragments in flight per wave
     static_assert(NF <= NB, "the fills of a block are issued between the K-blocks of one row quad");
     constexpr unsigned OOB = 0x80000000u;
-    static_assert(R >= 18 + 16 * D, "ring too small");
+    static_assert(R >= PR + 2 + PR * D, "ring too small");
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [R][ROWB] ring | 1 KiB scratch | [3][96] floats
 
     const aau_conv_desc& d = a.d;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
     const int fr = lane & 15, fk = lane >> 4;
     const int g = wave % G, slot = wave / G;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
-    const int tiles_y = d.H / 16;
+    const int tiles_y = d.H / PR;
 
     // ---- weights of this wave's 16-channel group: registers, once ----
     bf16x8 wr[3][NB];
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
         const int seg = u % nseg;
         const int t2 = u / nseg;
         const int strip = t2 % strips;
-        n = t2 / strips; x0 = strip * 16; ys = seg * segh * 16;
+        n = t2 / strips; x0 = strip * 16; ys = seg * segh * PR;
         K = tiles_y - seg * segh; if (K > segh) K = segh;
     };
 
@@ -154,18 +159,19 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
     // one LDS-DMA instruction (1 KiB: a quarter / half of a ring row) of the block under the issue cursor
     auto issue_one = [&](int i) {
         const bool live = iu < nunits;
-        const int idx = i * 12 + wave;
+        const int idx = i * FW + wave;
+        const bool real = wave < FW && idx < PR * IPR;                 // spare slots write zeros into the scratch KiB
         const int r = idx / IPR;                                       // row of the block (wave-uniform)
-        const int y = iys + 16 * ib + 1 + r;
-        const bool row_ok = live && idx < 16 * IPR && (unsigned)y < (unsigned)d.H && (ib >= 0 || r >= 14);
+        const int y = iys + PR * ib + 1 + r;
+        const bool row_ok = live && real && (unsigned)y < (unsigned)d.H && (ib >= 0 || r >= PR - 2);
         int rr = irb + r; if (rr >= R) rr -= R;
-        unsigned char* dstp = idx < 16 * IPR ? dsm + rr * ROWB + sub * 1024 : dsm + R * ROWB;
+        unsigned char* dstp = real ? dsm + rr * ROWB + sub * 1024 : dsm + R * ROWB;
         const unsigned soff = row_ok ? (unsigned)(((in_ * d.H + y) * d.W) * d.src_pitch * 2) : 0u;
         const unsigned v = (row_ok && !(abl & 2)) ? ivec : OOB;       // abl: timing ablations (AAU_C3S_ABL), never set in production
         if (!(abl & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, 0);
     };
     auto issue_end = [&]() {
-        irb += 16; if (irb >= R) irb -= R;
+        irb += PR; if (irb >= R) irb -= R;
         if (iu < nunits) {
             if (++ib == iK) { iu += gridDim.x; ib = -1; issue_unit_setup(); }
         }
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
     // per-channel epilogue constants of the inference form, staged once (no global loads between the fills and the stores)
     float* par = (float*)(dsm + R * ROWB + 1024);
     if (a.bias || a.scale) {
-        for (int i = tid; i < BQ; i += 768) {
+        for (int i = tid; i < BQ; i += 64 * NWV) {
             par[i] = a.bias ? a.bias[i] : 0.f;
             par[96 + i] = a.scale ? a.scale[i] : 1.f;
             par[192 + i] = a.scale ? a.shift[i] : 0.f;
@@ -200,6 +206,20 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
 
     int crb = 0;                               // ring row of block t
     bool prev_patch = false;
+    // STAGGER: the second half of the waves runs the epilogue of its LAST row quad of a patch behind the NEXT barrier, so
+    // that it overlaps with the first half's MFMAs (and the first half's epilogues with the second half's MFMAs) instead
+    // of all twelve waves doing their vector / store work at the same time with the matrix pipes idle.  The accumulators
+    // simply stay alive across the barrier.  (SIMD partners are waves w, w + 4, w + 8: every SIMD gets both kinds.)
+    const bool late = STAG && wave >= NWV / 2;
+    bool pend = false;
+    unsigned pend_soff = 0;
+    f32x4 acc[4];
+    auto epilogue = [&](unsigned soff0) {
+#pragma unroll
+        for (int mp = 0; mp < 4; mp += 2)
+            epi_pair_store(a, d, g * 16 + 4 * fk, acc[mp], acc[mp + 1], want_stats, s1, s2, dsm + par_off, rsD, st_voff,
+                           soff0 + (unsigned)(mp * d.W * d.dst_pitch * 2));
+    };
     for (int cu = blockIdx.x; cu < nunits; cu += gridDim.x) {
         int n, x0, ys, K;
         unit_decode(cu, n, x0, ys, K);
@@ -207,15 +227,19 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
             // block t has landed: the only younger operations are the fills of the blocks behind it and the previous
             // patch's stores (vmcnt retires in issue order)
             if (!(abl & 16)) {
-                if (prev_patch) wait_vm_s<NF * (D - 1) + NST>(); else wait_vm_s<NF * (D - 1)>();
+                // (a late wave's deferred stores were issued BEFORE the fills it waits for here)
+                if (!prev_patch) wait_vm_s<NF * (D - 1)>();
+                else if (late) wait_vm_s<NF * (D - 1) + NST - 2>();
+                else wait_vm_s<NF * (D - 1) + NST>();
                 __builtin_amdgcn_s_barrier();
             }
+            if (pend) { epilogue(pend_soff); pend = false; }
             // block t + D goes into rows nobody reads any more; on a patch step its NF instructions are issued between
             // the K-blocks of the first row quad instead of in one burst behind the barrier
             prev_patch = cb >= 0;
             if (cb < 0) issue_block();
             if (cb >= 0) {
-                const int y0 = ys + 16 * cb;
+                const int y0 = ys + PR * cb;
 #pragma unroll
                 for (int qi = 0; qi < NQ; ++qi) {
                     const int q = slot + qi * SLOTS;
@@ -226,7 +250,6 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
                         rr -= (rr >= 2 * R) ? 2 * R : (rr >= R ? R : 0);
                         va[r] = (unsigned)(rr * ROWB + lane_off);
                     }
-                    f32x4 acc[4];
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
                     // pixel fragments in program order s = 6 j + r, read PF ahead of their MFMAs
@@ -258,23 +281,22 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
                         if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 1.2345f) s1[0] += 1.f;
                         continue;
                     }
-#pragma unroll
-                    for (int mp = 0; mp < 4; mp += 2) {
-                        const unsigned soff = (unsigned)((((n * d.H + y0 + 4 * q + mp) * d.W) + x0) * d.dst_pitch * 2);
-                        epi_pair_store(a, d, g * 16 + 4 * fk, acc[mp], acc[mp + 1], want_stats, s1, s2, dsm + par_off, rsD, st_voff, soff);
-                    }
+                    const unsigned soff = (unsigned)((((n * d.H + y0 + 4 * q) * d.W) + x0) * d.dst_pitch * 2);
+                    if (late && qi == NQ - 1) { pend = true; pend_soff = soff; }
+                    else epilogue(soff);
                 }
             }
-            crb += 16; if (crb >= R) crb -= R;
+            crb += PR; if (crb >= R) crb -= R;
         }
     }
+    if (pend) epilogue(pend_soff);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (want_stats) {
         // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
         // fixed-point add per channel and workgroup (common.h: stat_add)
-        float* sst = (float*)dsm;                      // [12][2][BQ]
+        float* sst = (float*)dsm;                      // [NWV][2][BQ]
         __syncthreads();
-        for (int i = tid; i < 12 * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
+        for (int i = tid; i < NWV * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
         __syncthreads();
         float* mine = sst + wave * 2 * BQ;
 #pragma unroll
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(768) void conv3x3s_kernel(const C3Args a, int nunit
             }
         }
         __syncthreads();
-        stats_publish(sst, 12, BQ, tid, 0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
+        stats_publish(sst, NWV, BQ, tid, 0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
 }
 
@@ -305,32 +327,54 @@ bool conv3x3s_applicable(const aau_conv_desc* d, const void* src, const void* ds
 
 int conv3x3s_launch(C3Args& a, hipStream_t s) {
     const aau_conv_desc& d = a.d;
-    const int strips = d.W / 16, tiles_y = d.H / 16;
-    // cut the strips into vertical segments until every CU has a unit (each segment restarts the row stream: at least
-    // two patches per segment where the image allows it)
+    const bool c48 = d.Cin == 48, g3 = d.Cout == 48;
+    // two 6-wave workgroups per CU on 8-row patches (see the kernel), one 12-wave workgroup on 16-row patches otherwise
+    // (measured: two 6-wave workgroups per CU on 8-row patches are 20-30 % SLOWER -- twice the barriers, 10 halo rows per
+    // 8 -- so one 12-wave workgroup is the default and mode 2 an experiment switch)
+    int mode = 1;
+    if (const char* e = getenv("AAU_C3S_MODE")) mode = atoi(e);
+    const bool stag = getenv("AAU_C3S_STAG") != nullptr;      // staggered epilogues: measured 0-10 % slower, experiment only
+    const int PR = mode == 2 ? 8 : 16, per_cu = mode == 2 ? 2 : 1;
+    const int strips = d.W / 16, tiles_y = d.H / PR;
+    // cut the strips into vertical segments until every workgroup slot has a unit (each segment restarts the row stream:
+    // at least two patches per segment where the image allows it)
     int nseg = 1;
-    while ((int64_t)d.N * strips * nseg < 256 && tiles_y / (nseg * 2) >= 2) nseg *= 2;
+    while ((int64_t)d.N * strips * nseg < 256 * per_cu && tiles_y / (nseg * 2) >= 2) nseg *= 2;
     const int segh = (tiles_y + nseg - 1) / nseg;
     nseg = (tiles_y + segh - 1) / segh;
     const int64_t nunits = (int64_t)d.N * strips * nseg;
     if (nunits > 0x7fffffff) { set_error("conv3x3s: too many units"); return AAU_E_INVALID; }
-    const int grid = nunits < 256 ? (int)nunits : 256;
-    const bool c48 = d.Cin == 48, g3 = d.Cout == 48;
-    const size_t lds = (c48 ? (size_t)64 * 2048 : (size_t)36 * 4096) + 1024 + 3 * 96 * 4;
+    const int grid = nunits < 256 * per_cu ? (int)nunits : 256 * per_cu;
+    const size_t ring = mode == 2 ? (c48 ? (size_t)26 * 2048 : (size_t)18 * 4096) : (c48 ? (size_t)64 * 2048 : (size_t)36 * 4096);
+    const size_t lds = ring + 1024 + 3 * 96 * 4;
     int abl = 0;
     if (const char* e = getenv("AAU_C3S_ABL")) abl = atoi(e);       // timing ablations: 1 no MFMA, 2 fills out of range, 4 no stores, 8 no epilogue, 16 no barrier / wait, 32 no fill instructions
     prof_tag(c48 ? (g3 ? "conv3x3s<48,48>" : "conv3x3s<48,96>") : (g3 ? "conv3x3s<96,48>" : "conv3x3s<96,96>"));
-    auto go = [&](auto kern) {
+    auto go = [&](auto kern, int threads) {
         static bool attr = false;               // one flag per instantiation of this generic lambda
         if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, s, a, (int)nunits, strips, nseg, segh);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a, (int)nunits, strips, nseg, segh);
     };
     auto pick = [&](auto ablc) {
         constexpr int A = decltype(ablc)::value;
-        if (c48 && g3) go(conv3x3s_kernel<48, 3, A>);
-        else if (c48) go(conv3x3s_kernel<48, 6, A>);
-        else if (g3) go(conv3x3s_kernel<96, 3, A>);
-        else go(conv3x3s_kernel<96, 6, A>);
+        if (mode == 2) {
+            if (c48 && g3) go(conv3x3s_kernel<48, 3, 6, 8, A, false>, 384);
+            else if (c48) go(conv3x3s_kernel<48, 6, 6, 8, A, false>, 384);
+            else if (g3) go(conv3x3s_kernel<96, 3, 6, 8, A, false>, 384);
+            else go(conv3x3s_kernel<96, 6, 6, 8, A, false>, 384);
+        } else {
+            if (stag) {
+                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, true>, 768);
+                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, true>, 768);
+                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, true>, 768);
+                else go(conv3x3s_kernel<96, 6, 12, 16, A, true>, 768);
+            } else {
+                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, false>, 768);
+                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, false>, 768);
+                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, false>, 768);
+                else go(conv3x3s_kernel<96, 6, 12, 16, A, false>, 768);
+            }
+        }
     };
     switch (abl) {
 #ifdef AAU_C3S_ABLATE
