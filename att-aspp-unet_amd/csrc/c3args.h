@@ -17,6 +17,15 @@ struct C3Args {
     int nchunk;          // Cpad / 32
     unsigned src_bytes, wpk_bytes;
     int tiles_x, tiles_y;
+    // conv3x3s only (aau_conv_igemm_bnred): dst is the gradient dy of a BatchNorm -> ReLU layer whose raw conv output is
+    // bn_z; the epilogue then accumulates that layer's BatchNorm-backward sums (sum g, sum g * zhat, g = dy * relu') into
+    // `stats` instead of (sum v, sum v^2)
+    const unsigned short* bn_z = nullptr;
+    int bn_zp = 0;
+    const float* bn_scale = nullptr;
+    const float* bn_shift = nullptr;
+    const float* bn_mean = nullptr;
+    const float* bn_invstd = nullptr;
     int nowide;          // experiment (AAU_NO_WIDE_STORE): 8-byte epilogue stores
     int nopair;          // experiment (AAU_RESW_NOPAIR): no two-taps-per-K-block packing of a short last chunk
 };

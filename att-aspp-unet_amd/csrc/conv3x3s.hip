@@ -39,19 +39,36 @@ __device__ __forceinline__ void wait_vm_s() {
 // Epilogue of one pair of accumulator quads (c3args.h: epi_pair_wide) with the store as a buffer store: statistics, bias,
 // folded-BN affine (staged in LDS as [3][96] floats bias | scale | shift; par = this lane's channel quad in it) in the MFMA layout, the cross-lane swap, ReLU, one
 // 16-byte store at rsD[voff + soff].
+// BNRED: (zA, zB) are the 4 raw conv outputs of the CONSUMING BatchNorm layer at this lane's two pixels (MFMA layout); the
+// statistics are that layer's backward sums, par then holds [4][96] floats scale | shift | mean | invstd of that layer.
+template <bool BNRED>
 __device__ __forceinline__ void epi_pair_store(const C3Args& a, const aau_conv_desc& d, int q, const f32x4& accA, const f32x4& accB,
                                                bool want_stats, float s1[4], float s2[4], const unsigned char* par,
-                                               __amdgpu_buffer_rsrc_t rsD, unsigned voff, unsigned soff) {
+                                               __amdgpu_buffer_rsrc_t rsD, unsigned voff, unsigned soff, u32x2 zA = u32x2{0, 0},
+                                               u32x2 zB = u32x2{0, 0}) {
     float va[4], vb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { va[r] = accA[r]; vb[r] = accB[r]; }
-    if (want_stats) { epi_stats(a, 0, q, va, s1, s2); epi_stats(a, 0, q, vb, s1, s2); }
-    if (a.bias) {
+    if constexpr (BNRED) {
+        const f32x4 sc = *(const f32x4*)(par), sh = *(const f32x4*)(par + 384), mu = *(const f32x4*)(par + 768),
+                    is = *(const f32x4*)(par + 1152);
+        const float za[4] = {pair_lo(zA[0]), pair_hi(zA[0]), pair_lo(zA[1]), pair_hi(zA[1])};
+        const float zb[4] = {pair_lo(zB[0]), pair_hi(zB[0]), pair_lo(zB[1]), pair_hi(zB[1])};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // the gradient as the separate reduce pass would read it back: rounded to the 16-bit storage type
+            const float ga = (za[r] * sc[r] + sh[r] > 0.f) ? bf2f(f2bf(va[r])) : 0.f;
+            const float gb = (zb[r] * sc[r] + sh[r] > 0.f) ? bf2f(f2bf(vb[r])) : 0.f;
+            s1[r] += ga + gb;
+            s2[r] += ga * ((za[r] - mu[r]) * is[r]) + gb * ((zb[r] - mu[r]) * is[r]);
+        }
+    } else if (want_stats) { epi_stats(a, 0, q, va, s1, s2); epi_stats(a, 0, q, vb, s1, s2); }
+    if (!BNRED && a.bias) {
         const f32x4 b = *(const f32x4*)(par);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
     }
-    if (a.scale) {
+    if (!BNRED && a.scale) {
         const f32x4 sc = *(const f32x4*)(par + 384);
         const f32x4 sh = *(const f32x4*)(par + 768);
 #pragma unroll
@@ -72,7 +89,7 @@ __device__ __forceinline__ void epi_pair_store(const C3Args& a, const aau_conv_d
 // NWV waves per workgroup and PR patch rows: (12, 16) = one workgroup per CU, (6, 8) = TWO independent workgroups per CU
 // (half the ring each): while one of them sits in its barrier / epilogue / first-fragment latency the other one keeps the
 // matrix pipes busy -- with one workgroup per CU all twelve waves go through those phases together.
-template <int CIN, int G, int NWV, int PR, int ABL, bool STAG>
+template <int CIN, int G, int NWV, int PR, int ABL, bool STAG, bool BNRED>
 __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, int nunits, int strips, int nseg, int segh) {
     constexpr int abl = ABL;                           // timing ablations (AAU_C3S_ABL; builds with -DAAU_C3S_ABLATE only)
     constexpr int PXB = CIN == 48 ? 96 : 224;          // bytes per pixel in LDS
@@ -93,7 +110,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
     static_assert(NF <= NB, "the fills of a block are issued between the K-blocks of one row quad");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(R >= PR + 2 + PR * D, "ring too small");
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [R][ROWB] ring | 1 KiB scratch | [3][96] floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [R][ROWB] ring | 1 KiB scratch | [4][96] floats
 
     const aau_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -184,7 +201,12 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
 
     // per-channel epilogue constants of the inference form, staged once (no global loads between the fills and the stores)
     float* par = (float*)(dsm + R * ROWB + 1024);
-    if (a.bias || a.scale) {
+    if constexpr (BNRED) {
+        for (int i = tid; i < BQ; i += 64 * NWV) {
+            par[i] = a.bn_scale[i]; par[96 + i] = a.bn_shift[i]; par[192 + i] = a.bn_mean[i]; par[288 + i] = a.bn_invstd[i];
+        }
+        __syncthreads();
+    } else if (a.bias || a.scale) {
         for (int i = tid; i < BQ; i += 64 * NWV) {
             par[i] = a.bias ? a.bias[i] : 0.f;
             par[96 + i] = a.scale ? a.scale[i] : 1.f;
@@ -214,11 +236,32 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
     bool pend = false;
     unsigned pend_soff = 0;
     f32x4 acc[4];
+    // BNRED: the consuming layer's raw conv outputs at this lane's (pixel, 4 channels) of the four rows of the quad, loaded
+    // BEFORE the quad's MFMA stream (their latency hides behind it; they are older than the fills issued during the
+    // stream, so the compiler's wait for them leaves the fills in flight)
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(BNRED ? a.bn_z : a.dst), 0, 0x7fffffff, 0x00020000);
+    const unsigned z_voff = (unsigned)((fr * a.bn_zp + g * 16 + 4 * fk) * 2);
+    u32x2 zq[4];
+    auto load_z = [&](int n_, int y_, int x0_) {
+        if constexpr (BNRED) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                zq[mi] = __builtin_amdgcn_raw_buffer_load_b64(rsZ, (int)z_voff, (int)((((n_ * d.H + y_ + mi) * d.W) + x0_) * a.bn_zp * 2), 0);
+        }
+    };
     auto epilogue = [&](unsigned soff0) {
+        if constexpr (BNRED) {
+            // the z loads are followed by exactly the NF fills of this step (one row quad per wave in this form): wait for
+            // them by hand and make every later use of zq depend on the wait.  (hipcc's own count in front of the first use
+            // was too large by one with LDS-DMA builtins and asm waits in the stream: z landed late, into registers the
+            // allocator had already handed to the store data.)
+            static_assert(NQ == 1 && NF == 3, "the hand-counted wait below");
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(zq[0]), "+v"(zq[1]), "+v"(zq[2]), "+v"(zq[3]) : : "memory");
+        }
 #pragma unroll
         for (int mp = 0; mp < 4; mp += 2)
-            epi_pair_store(a, d, g * 16 + 4 * fk, acc[mp], acc[mp + 1], want_stats, s1, s2, dsm + par_off, rsD, st_voff,
-                           soff0 + (unsigned)(mp * d.W * d.dst_pitch * 2));
+            epi_pair_store<BNRED>(a, d, g * 16 + 4 * fk, acc[mp], acc[mp + 1], want_stats, s1, s2, dsm + par_off, rsD, st_voff,
+                                  soff0 + (unsigned)(mp * d.W * d.dst_pitch * 2), zq[mp], zq[mp + 1]);
     };
     for (int cu = blockIdx.x; cu < nunits; cu += gridDim.x) {
         int n, x0, ys, K;
@@ -250,6 +293,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
                         rr -= (rr >= 2 * R) ? 2 * R : (rr >= R ? R : 0);
                         va[r] = (unsigned)(rr * ROWB + lane_off);
                     }
+                    load_z(n, y0 + 4 * q, x0);
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
                     // pixel fragments in program order s = 6 j + r, read PF ahead of their MFMAs
@@ -333,6 +377,7 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
     // 8 -- so one 12-wave workgroup is the default and mode 2 an experiment switch)
     int mode = 1;
     if (const char* e = getenv("AAU_C3S_MODE")) mode = atoi(e);
+    if (a.bn_z) mode = 1;
     const bool stag = getenv("AAU_C3S_STAG") != nullptr;      // staggered epilogues: measured 0-10 % slower, experiment only
     const int PR = mode == 2 ? 8 : 16, per_cu = mode == 2 ? 2 : 1;
     const int strips = d.W / 16, tiles_y = d.H / PR;
@@ -346,7 +391,7 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
     if (nunits > 0x7fffffff) { set_error("conv3x3s: too many units"); return AAU_E_INVALID; }
     const int grid = nunits < 256 * per_cu ? (int)nunits : 256 * per_cu;
     const size_t ring = mode == 2 ? (c48 ? (size_t)26 * 2048 : (size_t)18 * 4096) : (c48 ? (size_t)64 * 2048 : (size_t)36 * 4096);
-    const size_t lds = ring + 1024 + 3 * 96 * 4;
+    const size_t lds = ring + 1024 + 4 * 96 * 4;
     int abl = 0;
     if (const char* e = getenv("AAU_C3S_ABL")) abl = atoi(e);       // timing ablations: 1 no MFMA, 2 fills out of range, 4 no stores, 8 no epilogue, 16 no barrier / wait, 32 no fill instructions
     prof_tag(c48 ? (g3 ? "conv3x3s<48,48>" : "conv3x3s<48,96>") : (g3 ? "conv3x3s<96,48>" : "conv3x3s<96,96>"));
@@ -355,24 +400,28 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
         if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a, (int)nunits, strips, nseg, segh);
     };
+    if (a.bn_z) {          // fused BatchNorm-backward sums (aau_conv_igemm_bnred): the default form only, 48 input channels
+        go(conv3x3s_kernel<48, 3, 12, 16, 0, false, true>, 768);      // 48 -> 48 (the 48 -> 96 form spills at 168 VGPRs)
+        return check_launch("aau_conv_igemm_bnred(3x3 strips)");
+    }
     auto pick = [&](auto ablc) {
         constexpr int A = decltype(ablc)::value;
         if (mode == 2) {
-            if (c48 && g3) go(conv3x3s_kernel<48, 3, 6, 8, A, false>, 384);
-            else if (c48) go(conv3x3s_kernel<48, 6, 6, 8, A, false>, 384);
-            else if (g3) go(conv3x3s_kernel<96, 3, 6, 8, A, false>, 384);
-            else go(conv3x3s_kernel<96, 6, 6, 8, A, false>, 384);
+            if (c48 && g3) go(conv3x3s_kernel<48, 3, 6, 8, A, false, false>, 384);
+            else if (c48) go(conv3x3s_kernel<48, 6, 6, 8, A, false, false>, 384);
+            else if (g3) go(conv3x3s_kernel<96, 3, 6, 8, A, false, false>, 384);
+            else go(conv3x3s_kernel<96, 6, 6, 8, A, false, false>, 384);
         } else {
             if (stag) {
-                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, true>, 768);
-                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, true>, 768);
-                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, true>, 768);
-                else go(conv3x3s_kernel<96, 6, 12, 16, A, true>, 768);
+                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, true, false>, 768);
+                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, true, false>, 768);
+                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, true, false>, 768);
+                else go(conv3x3s_kernel<96, 6, 12, 16, A, true, false>, 768);
             } else {
-                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, false>, 768);
-                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, false>, 768);
-                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, false>, 768);
-                else go(conv3x3s_kernel<96, 6, 12, 16, A, false>, 768);
+                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, false, false>, 768);
+                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, false, false>, 768);
+                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, false, false>, 768);
+                else go(conv3x3s_kernel<96, 6, 12, 16, A, false, false>, 768);
             }
         }
     };
@@ -390,3 +439,43 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
 }
 
 }  // namespace aau
+
+using namespace aau;
+
+namespace aau { bool conv3x3_applicable(const aau_conv_desc* d); }
+
+// 1 when aau_conv_igemm_bnred serves this descriptor: a 48 -> 48 channel 3x3 data-gradient conv that the strip kernel takes
+extern "C" int aau_conv_bnred_ok(const aau_conv_desc* d) {
+    if (!d || getenv("AAU_NO_BNRED")) return 0;
+    return conv3x3_applicable(d) && d->Cin == 48 && d->Cout == 48 && d->Cpad == 64 && !d->accumulate && !d->relu &&
+           d->src_pitch % 8 == 0 && d->dst_pitch % 8 == 0 && d->src_split_c <= 0 && d->dst_split_c <= 0 && !getenv("AAU_NO_C3S");
+}
+
+extern "C" int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst,
+                                    const aau_bf16* z, int z_pitch, const float* scale, const float* shift, const float* save_mean,
+                                    const float* save_invstd, aau_stat* sums, int64_t sums_bytes, void* stream) {
+    AAU_REQUIRE(d && src && wpk && dst && z && scale && shift && save_mean && save_invstd && sums, "aau_conv_igemm_bnred: null pointer");
+    AAU_REQUIRE(aau_conv_bnred_ok(d) && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && ((uintptr_t)z & 7) == 0 && z_pitch >= d->Cout &&
+                    z_pitch % 4 == 0,
+                "aau_conv_igemm_bnred: descriptor not served (aau_conv_bnred_ok) or misaligned operands");
+    AAU_CHECK_STAT("aau_conv_igemm_bnred", sums, sums_bytes, d->Cout);
+    const int64_t M = (int64_t)d->N * d->H * d->W;
+    const int64_t src_bytes = ((M - 1) * d->src_pitch + d->Cin) * 2, z_bytes = ((M - 1) * z_pitch + d->Cout) * 2;
+    AAU_REQUIRE(src_bytes < 0x7fffffff && z_bytes < 0x7fffffff && M * d->dst_pitch * 2 < 0x7fffffff,
+                "aau_conv_igemm_bnred: tensors must stay below 2 GiB");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(0, 2.0 * M * (double)d->Cout * d->Cin * 9, s);
+    prof_tag(nullptr, 2.0 * ((double)M * d->Cin + 2.0 * (double)M * d->Cout + (double)d->Cout * 9 * d->Cin));
+    C3Args a;
+    a.d = *d;
+    a.src = src; a.wpk = wpk; a.dst = dst; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr; a.stats = (float*)sums;
+    a.rev = next_traversal();
+    a.nchunk = d->Cpad / 32;
+    a.src_bytes = (unsigned)src_bytes;
+    a.wpk_bytes = (unsigned)((int64_t)d->Cout * 9 * d->Cpad * 2);
+    a.tiles_x = d->W / 16; a.tiles_y = d->H / 16;
+    a.nowide = 0; a.nopair = 0;
+    a.bn_z = z; a.bn_zp = z_pitch; a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = save_mean; a.bn_invstd = save_invstd;
+    return conv3x3s_launch(a, s);
+}
+

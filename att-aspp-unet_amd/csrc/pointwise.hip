@@ -731,6 +731,18 @@ extern "C" int aau_fold_stats(const aau_stat* stats, int64_t stats_bytes, int C,
                        which, c_begin, n, out);
     return check_launch("aau_fold_stats");
 }
+// out fp32 [2][C] = the totals of an aau_stat buffer (the `red` operand of the BatchNorm-backward apply passes)
+static __global__ void stats_to_f32_kernel(const long long* stats, int C, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * C) out[i] = (float)stat_total(stats, C, i / C, i % C);
+}
+extern "C" int aau_stats_to_red(const aau_stat* stats, int64_t stats_bytes, int C, float* red, void* stream) {
+    AAU_REQUIRE(stats && red && C > 0, "aau_stats_to_red: bad args");
+    AAU_CHECK_STAT("aau_stats_to_red", stats, stats_bytes, C);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(stats_to_f32_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, C, red);
+    return check_launch("aau_stats_to_red");
+}
 extern "C" int aau_stats_to_f64(const aau_stat* stats, int64_t stats_bytes, int C, double* out, void* stream) {
     AAU_REQUIRE(stats && out && C > 0, "aau_stats_to_f64: bad args");
     AAU_CHECK_STAT("aau_stats_to_f64", stats, stats_bytes, C);

@@ -344,7 +344,7 @@ class Plan:
         nbn = st.bn_channels + 8
         # order-independent fixed-point statistics (include/aau.h: aau_stat): int64 arenas, zeroed once per pass
         self.stats_arena = _Arena(STAT_REPLICAS * 4 * nbn + 4 * 64, self.dev, dtype=torch.int64)
-        self.bstats_arena = _Arena(STAT_REPLICAS * 4 * 48 * eng.store.convs["d1.0.block.0"].O + 64, self.dev,
+        self.bstats_arena = _Arena(STAT_REPLICAS * 4 * 56 * eng.store.convs["d1.0.block.0"].O + 64, self.dev,
                                    dtype=torch.int64) if train else None     # channel sums of dcat (4 levels x 3*Co)
         self.red_arena = _Arena(STAT_REPLICAS * 2 * nbn * 3 + STAT_REPLICAS * nbn * 3, self.dev)
         self.vec_arena = _Arena(nbn * 8 + 64, self.dev)
@@ -446,7 +446,10 @@ class Plan:
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
     def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, din_stats=None,
-                defer_wgrad=None, din_split=(0, 0), defer_dgrad=None):
+                defer_wgrad=None, din_split=(0, 0), defer_dgrad=None, red_next=None):
+        """``red_next``: the record of the ConvBNReLU layer whose output gradient is ``din`` (its only source): where the
+        library can (aau_conv_bnred_ok), the data-gradient conv below also accumulates THAT layer's BatchNorm-backward
+        sums in its epilogue and the layer's own reduce pass over (z, dy) is not recorded."""
         cv, bn, w = r["cv"], r["bn"], r["w"]
         N, H, W, M = r["N"], r["H"], r["W"], r["M"]
         b = self.bwd
@@ -463,7 +466,9 @@ class Plan:
                   bn.dbeta, M, cv.O, self.dlogits, head.w, w["scale"], w["shift"])
         elif dpool is None:
             # no pooling: the reduce pass only accumulates, the apply pass recomputes the ReLU / dropout mask
-            if r["z"] is None:      # first layer, z not stored
+            if r.get("red_done"):   # the sums came out of the producing data-gradient conv (red_next above)
+                pass
+            elif r["z"] is None:    # first layer, z not stored
                 b.add("aau_conv1_bn_bwd_reduce", r["src"], cv.w, dy, dyp, w["scale"], w["shift"], w["mean"],
                       w["invstd"], w["red"], N, H, W, cv.O, self.red_ws)
             else:
@@ -506,8 +511,19 @@ class Plan:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate, dst_split=din_split)
             # din_stats: [R][2][Cin] sums of the produced gradient (channel sums feed the ConvTranspose bias grad)
+            nr = red_next
+            fuse_red = (nr is not None and defer_dgrad is None and din_stats is None and nr.get("z") is not None
+                        and not nr["drop"] and nr.get("head") is None and nr["cv"].O == cv.I and dinp == cv.I
+                        and not self.eng.no_fuse_bnred and ops.conv_bnred_ok(dd))
             if defer_dgrad is not None:
                 defer_dgrad.append((dd, dz, cv.pk_d, din, b.label))     # emitted later as one grouped launch
+            elif fuse_red:
+                nw = nr["w"]
+                sums = self.bstats_arena.take(ops.stat_words(cv.I))
+                b.add("aau_conv_igemm_bnred", dd, dz, cv.pk_d, din, nr["z"], cv.I, nw["scale"], nw["shift"], nw["mean"],
+                      nw["invstd"], sums)
+                b.add("aau_stats_to_red", sums, cv.I, nw["red"])
+                nr["red_done"] = True
             else:
                 b.add("aau_conv_igemm", dd, dz, cv.pk_d, din, None, None, None, din_stats)
         return dz
@@ -700,7 +716,7 @@ class Plan:
         for blk in reversed(dec):            # u1, u2, u3, u4
             lv, Co, Mo, ho, wo, hi, wi = blk["lv"], blk["Co"], blk["Mo"], blk["ho"], blk["wo"], blk["hi"], blk["wi"]
             dya = self.new(Mo, Co)
-            self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co)
+            self.cbr_bwd(blk["rb"], dy, Co, din=dya, dinp=Co, red_next=blk["ra"])
             dcat = self.new(2, Mo, Co) if planar[lv] else self.new(Mo, 2 * Co)
             dcat_hi = hi_(dcat, lv)                # gradient of the transposed conv's output, pixel pitch cat_p[lv]
             # channel sums of dcat (fp32, from the data-gradient epilogue) -> ConvTranspose2d bias gradient below
@@ -828,7 +844,7 @@ class Plan:
             ra, rb = enc[lv]
             dsk, dskp = dskip[lv], dskip_p[lv]
             dya = self.new(Ms[lv], Cs[lv])
-            self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv])
+            self.cbr_bwd(rb, dsk, dskp, dpool=dpool, dpp=Cs[lv], din=dya, dinp=Cs[lv], red_next=ra)
             if lv > 0:
                 dprev = self.new(Ms[lv], Cs[lv - 1])
                 self.cbr_bwd(ra, dya, Cs[lv], din=dprev, dinp=Cs[lv - 1])
@@ -900,6 +916,7 @@ class Engine:
         self.no_fuse_colsum = os.environ.get("AAU_NO_FUSE_COLSUM", "0") == "1"
         self.no_fuse_head = os.environ.get("AAU_NO_FUSE_HEAD", "0") == "1"
         self.no_wgrad_group = os.environ.get("AAU_NO_WGRAD_GROUP", "0") == "1"
+        self.no_fuse_bnred = os.environ.get("AAU_NO_BNRED", "0") == "1"
         # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
         # reading the routed gradient the reduce pass stored
         self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"

@@ -172,6 +172,22 @@ def conv_igemm_group(descs, srcs, wpks, dst, ws=None):
     check(fn("aau_conv_igemm_group")(da, sa, wa, n, _p(dst), _p(ws), _stream()), "aau_conv_igemm_group")
 
 
+def conv_bnred_ok(desc: ConvDesc) -> bool:
+    return bool(fn("aau_conv_bnred_ok")(C.byref(desc)))
+
+
+def conv_igemm_bnred(desc: ConvDesc, src, wpk, dst, z, zp, scale, shift, smean, sinvstd, sums):
+    """Data-gradient conv + the BatchNorm-backward sums of the layer that consumes ``dst`` (include/aau.h)."""
+    _check_stats(sums, desc.Cout, "conv_igemm_bnred")
+    check(fn("aau_conv_igemm_bnred")(C.byref(desc), _p(src), _p(wpk), _p(dst), _p(z), zp, _p(scale), _p(shift), _p(smean),
+                                     _p(sinvstd), _p(sums), _nb(sums), _stream()), "aau_conv_igemm_bnred")
+
+
+def stats_to_red(stats, Cc, red):
+    _check_stats(stats, Cc, "stats_to_red")
+    check(fn("aau_stats_to_red")(_p(stats), _nb(stats), Cc, _p(red), _stream()), "aau_stats_to_red")
+
+
 def conv1_fwd(x, w, z, stats, N, H, W, Cc):
     _check_stats(stats, Cc, "conv1_fwd")
     check(fn("aau_conv1_fwd")(_p(x), _p(w), _p(z), _p(stats), _nb(stats), N, H, W, Cc, _stream()), "aau_conv1_fwd")

@@ -114,6 +114,19 @@ int aau_conv_igemm(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
                    aau_bf16* dst, const float* bias, const float* scale, const float* shift,
                    aau_stat* stats, int64_t stats_bytes, void* stream);
 
+/* A 3x3 data-gradient conv whose destination is the gradient dy of a [BatchNorm -> ReLU] layer (raw conv output z,  */
+/* folded scale / shift, saved mean / invstd of THAT layer): besides dst it accumulates that layer's BatchNorm-backward */
+/* sums  sum(g), sum(g * zhat),  g = bf16(dy) * [z*scale+shift > 0],  into `sums` (an aau_stat buffer for Cout channels,   */
+/* zeroed by the caller) -- the separate reduce pass of aau_bn_bwd_reduce over (z, dy) disappears (pipeline:59-65 backward).*/
+/* aau_stats_to_red turns the sums into the fp32 [2][C] `red` operand of the apply passes.  Served for the descriptors   */
+/* aau_conv_bnred_ok() accepts (48 -> 48 channels on the strip kernel).                                                  */
+int aau_conv_bnred_ok(const aau_conv_desc* d);
+int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst,
+                         const aau_bf16* z, int z_pitch, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_invstd, aau_stat* sums, int64_t sums_bytes,
+                         void* stream);
+int aau_stats_to_red(const aau_stat* stats, int64_t stats_bytes, int C, float* red, void* stream);
+
 /* 1 when the launch this descriptor selects supports its two-plane operands (src_split_c /  */
 /* dst_split_c): mode 0 = aau_conv_igemm (the resident-weight 3x3 kernels), 1 = aau_conv_wgrad */
 /* (wgrad3x3).  A descriptor with split operands that the selected kernel cannot serve fails   */

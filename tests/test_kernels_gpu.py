@@ -692,3 +692,49 @@ def test_strip_kernel_data_gradient_matches_conv2d_input(ops):
     assert [t.split(" ")[0] for t in lt] == ["conv3x3s<48,96>"], lt
     torch.cuda.synchronize()
     assert rel_err(din.cpu(), ref) < 6e-3
+
+
+def test_strip_data_gradient_with_fused_batchnorm_backward_sums(ops):
+    """aau_conv_igemm_bnred (48 -> 48): the data gradient is bit-identical to aau_conv_igemm's, and the sums its epilogue
+    accumulates for the consuming [BatchNorm -> ReLU] layer equal those of the separate aau_bn_bwd_reduce pass over (z, dy)."""
+    N, H, W, C_ = 2, 64, 80, 48
+    M = N * H * W
+    g = torch.Generator().manual_seed(21)
+    w = R.bf16_round(torch.randn(C_, C_, 3, 3, generator=g) / (C_ * 9) ** 0.5)
+    dz = R.bf16_round(torch.randn(N, H, W, C_, generator=g))
+    z = torch.randn(M, C_, generator=g).to(torch.bfloat16).cuda()            # raw conv output of the consuming layer
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.3
+    zf = z.float().cpu()
+    mean, var = zf.mean(0), zf.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    cpd = ops.cpad_of(C_)
+    dd = ops.conv_desc(N, H, W, C_, C_, H, W, C_, C_, 3, 3, 1, 1, 1, cpd)
+    assert ops.conv_bnred_ok(dd)
+    dzd, wd = dev(dz.to(torch.bfloat16)), dev(pack_dgrad(w, cpd))
+    ref = torch.empty(M, C_, dtype=torch.bfloat16, device="cuda")
+    ops.conv_igemm(dd, dzd, wd, ref)
+    out = torch.full((M, C_), float("nan"), dtype=torch.bfloat16, device="cuda")
+    sums = ops.stats_buffer(C_)
+    with launch_tags() as tags:
+        ops.conv_igemm_bnred(dd, dzd, wd, out, z, C_, dev(scale), dev(shift), dev(mean), dev(invstd), sums)
+    assert [t.split(" ")[0] for t in tags] == ["conv3x3s<48,48>"]
+    red = torch.zeros(2, C_, device="cuda")
+    ops.stats_to_red(sums, C_, red)
+    red_ref = torch.zeros(2, C_, device="cuda")
+    ops.bn_bwd_reduce(z, C_, ref, C_, None, 0, None, C_, dev(scale), dev(shift), dev(mean), dev(invstd), red_ref, N, H, W, C_)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    tol = 2e-4 * float(red_ref.abs().max()) + 1e-3
+    assert float((red - red_ref).abs().max()) < tol, (red - red_ref).abs().max()
+    # an independent fp64 check of the sums themselves
+    gz = ref.float().cpu().double() * ((zf * scale + shift) > 0)
+    s1 = gz.sum(0)
+    s2 = (gz * ((zf.double() - mean.double()) * invstd.double())).sum(0)
+    assert float((red[0].cpu().double() - s1).abs().max()) < 1e-3 * float(s1.abs().max()) + 1e-2
+    assert float((red[1].cpu().double() - s2).abs().max()) < 1e-3 * float(s2.abs().max()) + 1e-2
+    # run-to-run bitwise reproducible
+    sums2 = ops.stats_buffer(C_)
+    ops.conv_igemm_bnred(dd, dzd, wd, out, z, C_, dev(scale), dev(shift), dev(mean), dev(invstd), sums2)
+    torch.cuda.synchronize()
+    assert torch.equal(sums, sums2)
