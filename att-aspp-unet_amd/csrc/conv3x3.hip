@@ -1845,14 +1845,29 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
 // per-tile prologues, three exposed load waits and barriers (a no-store ablation of it still took 73 % of the
 // time).  Here the weights ([BQ][Cpad], <= 36 KB) stay in LDS, the activation tile of the next 256 pixels is in
 // flight while the current one is multiplied, and there is one barrier per 32-channel chunk.
-template <int BQ, int NW>
+// NBUF pixel tiles of one 32-channel chunk each form a ring; the fill of tile t + NBUF - 1 is issued while tile t is
+// multiplied.  Round 2 shipped NBUF = 2, i.e. ONE 16-KB tile of look-ahead per CU: at ~1.1 us from issue to landing that
+// caps a CU at ~15 GB/s (3.7 TB/s chip-wide; measured 2.2-3.4 TB/s on these byte-bound layers).  The weights of these
+// layers are small (<= 48 KB), so the ring can hold 7 tiles = 96 KB in flight per CU.
+// STAGED: the epilogue goes through LDS.  In the MFMA layout a lane owns 8 channels of one pixel: a wave-wide store is 64
+// pieces of 16 B in 64 different 96- / 192-byte rows (and for the ConvTranspose pixel shuffle in 64 different output
+// pixels, two pixels apart) -- timing ablations put 45 % of the transposed-conv time there.  Staged, the 256 x BQ tile is
+// written to LDS as 16-bit values and copied out so that a wave-wide store (or read-modify-write) covers one contiguous
+// KiB of the destination: whole 16-pixel rows, for the pixel shuffle whole 32-pixel output rows.
+template <int BQ, int NW, int NBUF, bool STAGED>
 __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, int npatch) {
-    constexpr int BK = 32, HW_ = 16, HROWS = HW_ * HW_, HPAD = 256, NI = BQ / 16, MI = 16 / NW, HL = 16 / NW;
+    constexpr int BK = 32, HW_ = 16, HROWS = HW_ * HW_, HPAD = 256, NI = BQ / 16, MI = 16 / NW;
+    // STAGED: the first half of the waves issues every fill, the second half every output store (and the read of an
+    // accumulating destination).  vmcnt retires in issue order, so a wave that mixes both waits for its stores' write
+    // acknowledgements (and for a read-modify-write's loads, behind ALL its fills) before it may touch a landed tile.
+    constexpr int NWF = STAGED ? NW / 2 : NW;          // waves that fill
+    constexpr int HL = 16 / NWF;
     constexpr int HALO_E = HPAD * BK, WT_E = BQ * BK;
     constexpr unsigned OOB = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];   // [2 pixel tiles][nchunk weight tiles]
+    extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];   // [NBUF pixel tiles][nchunk weight tiles]
+    constexpr int PD = NBUF - 1;                     // tiles in flight
     auto sH = [&](int b) -> unsigned short* { return dsm + b * HALO_E; };
-    auto sWt = [&](int chunk) -> unsigned short* { return dsm + 2 * HALO_E + chunk * WT_E; };
+    auto sWt = [&](int chunk) -> unsigned short* { return dsm + NBUF * HALO_E + chunk * WT_E; };
 
     const aau_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -1874,7 +1889,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             const int chunk = tile;
             const bool ok = tile < ntile && q0 + row < d.Cout;
             const unsigned v = ok ? (unsigned)(((q0 + row) * d.Cpad + chunk * BK + lc * 8) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dsm + 2 * HALO_E + (base + wave * 64) * 8), 16, (int)v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dsm + NBUF * HALO_E + (base + wave * 64) * 8), 16, (int)v, 0, 0, 0);
         }
     }
     // ---- halo roles (patch independent part) ----
@@ -1883,7 +1898,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
     const int tail_c0 = (a.nchunk - 1) * BK;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-        const int hr = (i * NW + wave) * 16 + (lane >> 2);
+        const int hr = (i * NWF + wave) * 16 + (lane >> 2);
         lc_[i] = swz32(hr, lane & 3);
         hy_[i] = hr < HROWS ? hr / HW_ : -100000;
         hx_[i] = hr % HW_;
@@ -1906,11 +1921,26 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             const int y = y0 + hy_[i], x = x0 + hx_[i];
             const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
             const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * NW + wave) * 16 * BK), 16, (int)v,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * NWF + wave) * 16 * BK), 16, (int)v,
                                                      chunk * BK * 2, 0, 0);
         }
     };
 
+    // per-channel epilogue vectors (bias, folded-BN scale / shift) staged in LDS behind the weight tiles: a global load in
+    // the epilogue would wait for every fill in flight (vmcnt retires in order)
+    // (behind the ROUNDED weight area: the staging loop above writes whole 8-KiB rounds, zeros past the last tile)
+    float* par = (float*)((unsigned char*)dsm + NBUF * HALO_E * 2 + ((size_t)a.nchunk * BQ * 64 + 8191) / 8192 * 8192);   // [3][BQ]
+    if (a.bias || a.scale) {
+        const int Co_ = d.shuffle2x2 ? d.Cout >> 2 : d.Cout;
+        for (int i = tid; i < BQ; i += 64 * NW) {
+            const int q = q0 + i;
+            const int qv = q < d.Cout ? (d.shuffle2x2 ? q % Co_ : q) : 0;
+            par[i] = a.bias ? a.bias[qv] : 0.f;
+            par[BQ + i] = a.scale ? a.scale[qv] : 1.f;
+            par[2 * BQ + i] = a.scale ? a.shift[qv] : 0.f;
+        }
+        __syncthreads();
+    }
     constexpr bool STATS = true;
     constexpr int NS = STATS ? NI : 1;
     const bool want_stats = STATS && a.stats != nullptr;
@@ -1925,7 +1955,24 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
     // 16-byte epilogue stores (common.h: swap_pair8) when the destination allows them
     const bool wide = ((uintptr_t)a.dst & 15) == 0 && d.dst_pitch % 8 == 0 && (!d.shuffle2x2 || (d.Cout >> 2) % 8 == 0) && !a.nowide;
     int t = 0;
-    if (first < npatch) issue_halo(0, first, 0);
+    // fill cursor: (patch, chunk) of the next tile to issue; the ring runs PD tiles ahead of the multiply
+    int fp = first, fc = 0, fb = 0;
+    const bool filler = wave < NWF;
+    auto issue_next = [&]() {
+        if (filler) {
+            if (fp < npatch) issue_halo(fb, fp, fc);
+            else {                               // past the end: keep every filling wave's instruction count the same
+#pragma unroll
+                for (int i = 0; i < HL; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(fb) + (i * NWF + wave) * 16 * BK), 16, (int)OOB, 0, 0, 0);
+            }
+        }
+        if (++fc == a.nchunk) { fc = 0; fp += stride; }
+        if (++fb == NBUF) fb = 0;
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue_next();
+    int cb = 0;                                  // ring slot of tile t
     for (int patch = first; patch < npatch; patch += stride) {
         f32x4 acc[NI][MI];
 #pragma unroll
@@ -1936,24 +1983,33 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             // halo(t) (and, the first time, the weights) must have landed.  At the first chunk of a later
             // patch the only younger operations are the previous patch's NI*MI output stores per lane
             // (vmcnt retires in issue order), which may stay in flight.
-            if (t > 0 && chunk == 0 && full_tiles && wide) {          // half as many (16-byte) stores per lane
-                if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            } else if (t > 0 && chunk == 0 && full_tiles) {
-                if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            } else {
+            // tile t must have landed: the younger operations are the fills of tiles t+1 .. t+PD-1 (HL instructions per
+            // wave each) and output stores issued between them; waiting down to the fills alone is exact when no store
+            // is younger than tile t and at worst also retires a few fills that were issued PD-2 steps ago
+            if constexpr (PD == 1 && STAGED) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if constexpr (PD == 1) {
+                if (t > 0 && chunk == 0 && full_tiles && wide) {          // half as many (16-byte) stores per lane
+                    if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                } else if (t > 0 && chunk == 0 && full_tiles) {
+                    if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                static_assert(PD == 1 || (PD - 1) * HL == 10 || (PD - 1) * HL == 8, "immediates below");
+                if (!filler) { if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // its share of the weight tiles
+                else if constexpr ((PD - 1) * HL == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
-            {   // prefetch the next (patch, chunk) tile into the other buffer
-                int np = patch, nc = chunk + 1;
-                if (nc == a.nchunk) { nc = 0; np += stride; }
-                if (np < npatch) issue_halo((t + 1) & 1, np, nc);
-            }
-            const unsigned short* hbase = sH(t & 1);
+            issue_next();                        // tile t + PD, into the slot tile t - 1 has just left
+            const unsigned short* hbase = sH(cb);
+            if (++cb == NBUF) cb = 0;
             {
                 constexpr int ty = 0, tx = 0;
                 const unsigned short* wbase = sWt(chunk);
@@ -1984,6 +2040,85 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
         // ---- per-patch epilogue ----
         int n, y0, x0;
         patch_origin(patch, n, y0, x0);
+        if constexpr (STAGED) {
+            constexpr int PXS = BQ * 2 + 16;                         // LDS bytes per staged pixel (+16: bank spread)
+            unsigned char* sO = (unsigned char*)par + 3 * BQ * 4;   // [256 px][PXS]
+            // 1. every lane: its accumulators (+ bias / affine, statistics) as 16-bit values, 8 channels of one pixel per piece
+#pragma unroll
+            for (int mp = 0; mp < MI; mp += 2) {
+                const int rl = wave * MI + mp + (fk & 1);            // patch row this lane owns after the swap
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int q = q0 + ni * 16 + 4 * fk;
+                    float va[4], vb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { va[r] = acc[ni][mp][r]; vb[r] = acc[ni][mp + 1][r]; }
+                    if (q < d.Cout) {
+                        if (want_stats) { epi_stats(a, 0, q, va, s1[ni], s2[ni]); epi_stats(a, 0, q, vb, s1[ni], s2[ni]); }
+                        const int ql = ni * 16 + 4 * fk;
+                        if (a.bias) {
+                            const f32x4 b = *(const f32x4*)(par + ql);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
+                        }
+                        if (a.scale) {
+                            const f32x4 sc = *(const f32x4*)(par + BQ + ql);
+                            const f32x4 sh = *(const f32x4*)(par + 2 * BQ + ql);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
+                        }
+                    }
+                    float w[8];
+                    swap_pair8(va, vb, w);
+                    *(u32x4*)(sO + (rl * 16 + fr) * PXS + (ni * 16 + 8 * (fk >> 1)) * 2) = pack8(w);
+                }
+            }
+            __syncthreads();
+            // 2. copy out: piece p = (pixel, 8-channel part) in DESTINATION order
+            constexpr int PARTS = BQ / 8;
+            const int Co = d.Cout >> 2;
+            for (int p = tid - 64 * NWF; p >= 0 && p < 256 * PARTS; p += 64 * (NW - NWF)) {
+                int px, part;
+                unsigned short* out;
+                if (d.shuffle2x2) {
+                    // order [patch row][output row of the pair, when the tile holds both][input pixel x][its parts]: a
+                    // wave-wide store runs along ONE output row (channel tiles never straddle an output row: host check)
+                    const int norow = BQ >= 4 * Co ? 2 : 1, ppr = PARTS / norow;
+                    const int yy = p / (norow * 16 * ppr), rem = p - yy * (norow * 16 * ppr);
+                    const int orow = rem / (16 * ppr), rem2 = rem - orow * (16 * ppr);
+                    const int xx = rem2 / ppr, pp = rem2 - xx * ppr;
+                    px = yy * 16 + xx; part = orow * ppr + pp;
+                    const int qw = q0 + part * 8;
+                    if (qw >= d.Cout) continue;
+                    const int pos = qw / Co;
+                    const int64_t op = ((int64_t)n * (2 * d.H) + (2 * (y0 + yy) + (pos >> 1))) * (2 * d.W) + (2 * (x0 + xx) + (pos & 1));
+                    out = a.dst + op * d.dst_pitch + (qw - pos * Co);
+                } else {
+                    px = p / PARTS; part = p - px * PARTS;
+                    const int qw = q0 + part * 8;
+                    if (qw >= d.Cout) continue;
+                    out = a.dst + (((int64_t)n * d.H + y0 + (px >> 4)) * d.W + x0 + (px & 15)) * d.dst_pitch + qw;
+                }
+                u32x4 v = *(const u32x4*)(sO + px * PXS + part * 16);
+                if (d.accumulate || d.relu) {
+                    float w[8];
+                    unpack8(v, w);
+                    if (d.accumulate) {
+                        float o[8];
+                        unpack8(*(const u32x4*)out, o);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) w[r] += o[r];
+                    }
+                    if (d.relu) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
+                    }
+                    v = pack8(w);
+                }
+                *(u32x4*)out = v;
+            }
+            continue;
+        }
         if (wide) {
             static_assert(MI % 2 == 0, "pixel rows are stored in pairs");
             const int Co = d.Cout >> 2;
@@ -2001,15 +2136,15 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
                         if constexpr (STATS) {
                             if (want_stats) { epi_stats(a, 0, q, va, s1[ni], s2[ni]); epi_stats(a, 0, q, vb, s1[ni], s2[ni]); }
                         }
-                        const int qv = d.shuffle2x2 ? q % Co : q;
+                        const int ql = ni * 16 + 4 * fk;             // channel inside this workgroup's tile
                         if (a.bias) {
-                            const f32x4 b = *(const f32x4*)(a.bias + qv);
+                            const f32x4 b = *(const f32x4*)(par + ql);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
                         }
                         if (a.scale) {
-                            const f32x4 sc = *(const f32x4*)(a.scale + qv);
-                            const f32x4 sh = *(const f32x4*)(a.shift + qv);
+                            const f32x4 sc = *(const f32x4*)(par + BQ + ql);
+                            const f32x4 sh = *(const f32x4*)(par + 2 * BQ + ql);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
                         }
@@ -2156,21 +2291,44 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     const int ntq = (d->Cout + BQ - 1) / BQ;
     const int npatch = a.tiles_x * a.tiles_y * d->N;
     const size_t wbytes = ((size_t)a.nchunk * BQ * 64 + 8191) / 8192 * 8192;   // whole staging rounds of 512 threads
-    const size_t lds = (size_t)2 * 256 * 64 + wbytes;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)conv1x1_resw_kernel<48, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)conv1x1_resw_kernel<96, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    // LDS: ring of pixel tiles (16 KB each) | weights | per-channel vectors | (staged form) the 256 x BQ output tile.
+    // Staged epilogue (coalesced stores) needs 16-byte-aligned rows; the pixel shuffle needs the whole 4 Co channels in one
+    // tiles must not straddle an output row of the 2x2 pair (BQ = 4 Co, or BQ dividing 2 Co).
+    const size_t stage = (size_t)256 * (BQ * 2 + 16);
+    const bool aligned = ((uintptr_t)dst & 15) == 0 && d->dst_pitch % 8 == 0 && d->Cout % 8 == 0;
+    const int Co4 = d->Cout >> 2;
+    bool staged = aligned && (!d->shuffle2x2 || (Co4 % 8 == 0 && (BQ == 4 * Co4 || (2 * Co4) % BQ == 0))) &&
+                  getenv("AAU_PW_STAGE") && !getenv("AAU_NO_WIDE_STORE");
+    // (measured, round 3: the LDS-staged coalesced epilogue is 0-15 % SLOWER than the per-lane 16-byte stores on every
+    // layer that takes this kernel, with or without the fill / store role split -- the stores are not what bounds it;
+    // the deeper ring alone gives 5-8 %.  Staged form = experiment switch AAU_PW_STAGE=1.)
+    int nbuf = staged ? 4 : 7;
+    if ((size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + (staged ? stage : 0) > 160 * 1024) { nbuf = 2; }
+    if ((size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + (staged ? stage : 0) > 160 * 1024) { staged = false; }
+    if (const char* e = getenv("AAU_PW_NBUF")) { if (atoi(e) == 2) { nbuf = 2; staged = false; } }   // experiment: round-2 form
+    const size_t lds = (size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + (staged ? stage : 0);
     int per_cu = lds <= 80 * 1024 ? 2 : 1;
     if (const char* e = getenv("AAU_PW_PERCU")) per_cu = atoi(e);   // experiment
     int gx = 256 * per_cu / ntq;
     if (gx > npatch) gx = npatch;
     if (gx < 1) gx = 1;
     prof_tag(BQ == 48 ? "conv1x1_resw<48>" : "conv1x1_resw<96>");
-    if (BQ == 48) hipLaunchKernelGGL((conv1x1_resw_kernel<48, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
-    else hipLaunchKernelGGL((conv1x1_resw_kernel<96, 8>), dim3(gx, ntq), dim3(512), lds, s, a, npatch);
+    auto go = [&](auto kern) {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(kern, dim3(gx, ntq), dim3(512), lds, s, a, npatch);
+    };
+    if (BQ == 48) {
+        if (staged && nbuf == 4) go(conv1x1_resw_kernel<48, 8, 4, true>);
+        else if (staged) go(conv1x1_resw_kernel<48, 8, 2, true>);
+        else if (nbuf == 7) go(conv1x1_resw_kernel<48, 8, 7, false>);
+        else go(conv1x1_resw_kernel<48, 8, 2, false>);
+    } else {
+        if (staged && nbuf == 4) go(conv1x1_resw_kernel<96, 8, 4, true>);
+        else if (staged) go(conv1x1_resw_kernel<96, 8, 2, true>);
+        else if (nbuf == 7) go(conv1x1_resw_kernel<96, 8, 7, false>);
+        else go(conv1x1_resw_kernel<96, 8, 2, false>);
+    }
     return check_launch("aau_conv_igemm(1x1 resident weights)");
 }
 
