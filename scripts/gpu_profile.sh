@@ -2,7 +2,7 @@
 # Profile call: full GPU suite, bench line, kernel trace + PMC passes of the real step, per-layer micro-benchmark; usage: gpu_profile.sh <tag>
 set -o pipefail
 R=$PWD
-O=$R/gpurun_out/${1:-r2p}
+O=$R/gpurun_out/${1:-r3p}
 mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
