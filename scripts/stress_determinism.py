@@ -26,9 +26,11 @@ tot = 0
 tot += run_case("conv3x3g<96> 64x64 768->384", 8, 64, 64, 768, 384, 3, 1)
 tot += run_case("conv3x3g<96> 128x128 96->192", 8, 128, 128, 96, 192, 3, 1)
 tot += run_case("conv3x3g<48> small 48->48", 2, 64, 64, 48, 48, 3, 1)
-tot += run_case("resw<48> 512 48->48", 8, 512, 512, 48, 48, 3, 1, reps=12)
-tot += run_case("resw<48> 512 96->48", 8, 512, 512, 96, 48, 3, 1, reps=12)
-tot += run_case("resw<96> 256 48->96", 8, 256, 256, 48, 96, 3, 1, reps=12)
+tot += run_case("conv3x3s<48,48> 512 48->48", 8, 512, 512, 48, 48, 3, 1, reps=12)
+tot += run_case("conv3x3s<96,48> 512 96->48", 8, 512, 512, 96, 48, 3, 1, reps=12)
+tot += run_case("conv3x3s<48,96> 256 48->96", 8, 256, 256, 48, 96, 3, 1, reps=12)
+tot += run_case("conv3x3s<96,96> 256 96->96", 8, 256, 256, 96, 96, 3, 1, reps=12)
+tot += run_case("resw<48> 256 64->48 (round-2 kernel)", 8, 256, 256, 64, 48, 3, 1, reps=12)
 tot += run_case("igemm dil6 32x32 384->768", 8, 32, 32, 384, 768, 3, 6)
 tot += run_case("igemm SMALL dgrad-like 768->384 d12", 8, 32, 32, 768, 384, 3, 12)
 tot += run_case("igemm 1x1 3840->768", 8, 32, 32, 3840, 768, 1, 1)
@@ -88,6 +90,34 @@ def run_group(name, reps=30):
 tot += run_group("igemm_group bridge dgrad")
 tot += run_case("igemm wide convT-like 768->1536", 8, 32, 32, 768, 1536, 1, 1)
 tot += run_case("igemm wide dil18 384->768", 8, 32, 32, 384, 768, 3, 18)
-tot += run_case("resw2 paired 512 48->48", 8, 512, 512, 48, 48, 3, 1, reps=12)
+
+
+def run_bnred(name, reps=12):
+    """strip input gradient with the fused BatchNorm-backward sums (hand-counted vmcnt for the z loads): outputs AND sums"""
+    N, H, W, C_ = 8, 512, 512, 48
+    dz = torch.randn(N, H, W, C_, device="cuda").to(torch.bfloat16)
+    z = torch.randn(N * H * W, C_, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(C_, 9, 64, device="cuda") / (C_ * 9) ** 0.5).to(torch.bfloat16)
+    w[:, :, C_:] = 0
+    sc, sh = torch.rand(C_, device="cuda") + 0.5, torch.randn(C_, device="cuda") * 0.3
+    mu, istd = torch.zeros(C_, device="cuda"), torch.ones(C_, device="cuda")
+    d = ops.conv_desc(N, H, W, C_, C_, H, W, C_, C_, 3, 3, 1, 1, 1, 64)
+    other = torch.randn(64 << 20, device="cuda")
+    outs, sums = [], []
+    for r in range(reps):
+        out = torch.full((N * H * W, C_), float("nan"), dtype=torch.bfloat16, device="cuda")
+        st = ops.stats_buffer(C_)
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_igemm_bnred(d, dz, w, out, z, C_, sc, sh, mu, istd, st)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(out); sums.append(st)
+    torch.cuda.synchronize()
+    bad = sum(0 if (torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) and torch.equal(s_, sums[0])) else 1
+              for o, s_ in zip(outs[1:], sums[1:]))
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0].float()).sum())}", flush=True)
+    return bad
+
+
+tot += run_bnred("conv3x3s bnred 512 48->48")
 tot += run_case("conv1x1_resw 256 96->48", 8, 256, 256, 96, 48, 1, 1, reps=12)
 print("TOTAL mismatches", tot)
