@@ -150,3 +150,49 @@ def test_engine_step_under_data_parallel_world2_matches_mean_of_per_rank_referen
         assert np.abs(res[r]["sd"][k] - ref_rm).max() < 4e-2 * np.abs(ref_rm).max() + 1e-4
     # 5. the dropout seed chain is mixed with the rank
     assert res[0]["drop_seed"] != res[1]["drop_seed"]
+
+
+def _train_worker(rank, world, port, out_dir, q):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import att_aspp_unet_amd as A
+        torch.cuda.set_device(0)
+        args = A.pipeline.get_args(["train", "--epochs", "3", "--batch_size", "4", "--base_c", "8", "--img_size", "64",
+                                    "--synthetic_batches", "6", "--output_dir", out_dir, "--seed", "11"])
+        model, hist = A.train(args)
+        torch.cuda.synchronize()
+        q.put(dict(rank=rank, hist=hist, w=model.engine.store.flat.detach().cpu().numpy(),
+                   rm=model.state_dict()["d1.1.block.1.running_mean"].cpu().numpy()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(dict(rank=rank, error=f"{e!r}\n{traceback.format_exc()}"))
+
+
+def test_train_loop_under_data_parallel_makes_collective_decisions(tmp_path):
+    """pipeline:316-333 with two ranks: every rank trains on its own synthetic shard, the epoch's validation
+    score and BatchNorm buffers are rank 0's on every rank (broadcast), so best-checkpoint / early-stop decisions agree and
+    nobody is left waiting in an all-reduce; weights stay identical; only rank 0 writes the checkpoint."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world, port = 2, _free_port()
+    ctx = torch.multiprocessing.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, str(tmp_path / "ck"), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=420) for _ in range(world)], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=120)
+    assert all("error" not in r for r in res), [r.get("error") for r in res]
+    h0, h1 = res[0]["hist"], res[1]["hist"]
+    assert len(h0) == len(h1) == 3
+    for a, b in zip(h0, h1):
+        assert a[1] == b[1] and a[2] == b[2]                 # validation Dice / IoU: rank 0's values on both ranks
+        assert a[0] != b[0]                                  # the training loss is each rank's own shard's
+    assert np.array_equal(res[0]["w"], res[1]["w"])          # identical weights after every step
+    assert np.array_equal(res[0]["rm"], res[1]["rm"])        # buffers were synchronised for validation
+    assert len(list((tmp_path / "ck" / "ckpt_main").glob("best_*.pt"))) >= 1
