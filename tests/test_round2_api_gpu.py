@@ -292,3 +292,31 @@ def test_experiment_switches_do_not_change_the_result(A, switch, monkeypatch):
         assert abs(la - lb) <= 1e-5 * abs(la)
         cos = torch.nn.functional.cosine_similarity(ga, gb, dim=0)
         assert float(cos) > 0.9999 and abs(float(ga.norm() / gb.norm()) - 1) < 1e-3
+
+
+def test_gradient_accumulation_over_forward_backward_pairs(A):
+    """torch semantics of ``.grad``: two forward / backward pairs without clearing the gradients in between ADD; clearing
+    them (set_to_none, the default of optimisers and of Module.zero_grad) starts afresh.  Bitwise: g(a) + g(b)."""
+    from att_aspp_unet_amd import synth
+    m = _tiny(A, p_drop=0.0)
+    crit = A.build_criterion(Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05), A.ComboLoss(), A.EdgeLoss())
+    xa, ya = (t.cuda() for t in synth.make_frames(2, 64, seed=3, force_pattern="pn"))
+    xb, yb = (t.cuda() for t in synth.make_frames(2, 64, seed=4, force_pattern="pp"))
+    opt = A.FusedAdamW(m, lr=0.0)
+
+    def grads(x, y):
+        opt.zero_grad()
+        crit(m(x), y).backward()
+        return m.engine.store.gflat.clone()
+    ga, gb = grads(xa, ya), grads(xb, yb)
+    assert not torch.equal(ga, gb)
+    opt.zero_grad()
+    crit(m(xa), ya).backward()
+    crit(m(xb), yb).backward()                      # no zero_grad in between: accumulates
+    acc = m.engine.store.gflat
+    assert torch.equal(acc, ga + gb)
+    p = dict(m.named_parameters())["d2.0.block.0.weight"]
+    assert p.grad is not None and torch.equal(p.grad, m.engine.store.gviews["d2.0.block.0.weight"])
+    m.zero_grad()                                   # Module.zero_grad: set_to_none -> the next backward starts afresh
+    crit(m(xa), ya).backward()
+    assert torch.equal(m.engine.store.gflat, ga)
