@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
 // pixels, two pixels apart) -- timing ablations put 45 % of the transposed-conv time there.  Staged, the 256 x BQ tile is
 // written to LDS as 16-bit values and copied out so that a wave-wide store (or read-modify-write) covers one contiguous
 // KiB of the destination: whole 16-pixel rows, for the pixel shuffle whole 32-pixel output rows.
-template <int BQ, int NW, int NBUF, bool STAGED>
+template <int BQ, int NW, int NBUF, bool STAGED, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, int npatch) {
     constexpr int BK = 32, HW_ = 16, HROWS = HW_ * HW_, HPAD = 256, NI = BQ / 16, MI = 16 / NW;
     // STAGED: the first half of the waves issues every fill, the second half every output store (and the read of an
@@ -1920,7 +1920,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
         for (int i = 0; i < HL; ++i) {
             const int y = y0 + hy_[i], x = x0 + hx_[i];
             const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W && !(last && !htail[i]);
-            const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;
+            const unsigned v = (ok && !(ABL & 2)) ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + lc_[i] * 8) * 2) : OOB;   // ABL: timing ablations (-DAAU_C3S_ABLATE builds)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(buf) + (i * NWF + wave) * 16 * BK), 16, (int)v,
                                                      chunk * BK * 2, 0, 0);
         }
@@ -2171,7 +2171,8 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
 #pragma unroll
                         for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
                     }
-                    *(u32x4*)out = pack8(w);
+                    if (!(ABL & 4)) *(u32x4*)out = pack8(w);
+                    else if (w[0] == 1.2345f) *(u32x4*)out = pack8(w);
                 }
             }
             continue;
@@ -2329,6 +2330,18 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
         else if (nbuf == 7) go(conv1x1_resw_kernel<96, 8, 7, false>);
         else go(conv1x1_resw_kernel<96, 8, 2, false>);
     }
+#ifdef AAU_C3S_ABLATE
+    // (the launch above already ran; an ablation run times BOTH and the difference is what the switch removes)
+    if (const char* e = getenv("AAU_PW_ABL")) {
+        const int abl = atoi(e);
+        if (BQ == 96 && abl == 2) go(conv1x1_resw_kernel<96, 8, 7, false, 2>);
+        if (BQ == 96 && abl == 4) go(conv1x1_resw_kernel<96, 8, 7, false, 4>);
+        if (BQ == 96 && abl == 6) go(conv1x1_resw_kernel<96, 8, 7, false, 6>);
+        if (BQ == 48 && abl == 2) go(conv1x1_resw_kernel<48, 8, 7, false, 2>);
+        if (BQ == 48 && abl == 4) go(conv1x1_resw_kernel<48, 8, 7, false, 4>);
+        if (BQ == 48 && abl == 6) go(conv1x1_resw_kernel<48, 8, 7, false, 6>);
+    }
+#endif
     return check_launch("aau_conv_igemm(1x1 resident weights)");
 }
 

@@ -332,12 +332,20 @@ def main():
         return launch_selftest(world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # AAU_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (the ranks then share
+    # the cards; RCCL refuses two ranks on one device).  Never the measured configuration.
+    backend = os.environ.get("AAU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import att_aspp_unet_amd as A
     from att_aspp_unet_amd import _abi, synth
@@ -394,16 +402,21 @@ def main():
     loss_val = float(loss.item())
 
     roof = None
-    if not a.no_roofline and rank == 0:
-        # second pass of the same steps (eager launch list) with every launch bracketed by HIP events on its stream
+    if not a.no_roofline:
+        # second pass of the same steps (eager launch list) with every launch bracketed by HIP events on its stream.
+        # EVERY rank runs these steps (a data-parallel step contains collectives: rank 0 alone would wait for peers that
+        # have moved on); only rank 0 records.
         nprof = min(a.steps, 5)
         step(x, y)
         torch.cuda.synchronize()
-        _abi.prof_enable(True)
+        if rank == 0:
+            _abi.prof_enable(True)
         for i in range(nprof):
             step(x, y)
         torch.cuda.synchronize()
-        _abi.prof_enable(False)
+        if rank == 0:
+            _abi.prof_enable(False)
+    if not a.no_roofline and rank == 0:
         recs = _abi.prof_collect_launches()
         if a.dump_launches and len(recs) % nprof == 0:
             per = len(recs) // nprof

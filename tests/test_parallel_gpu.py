@@ -196,3 +196,25 @@ def test_train_loop_under_data_parallel_makes_collective_decisions(tmp_path):
     assert np.array_equal(res[0]["w"], res[1]["w"])          # identical weights after every step
     assert np.array_equal(res[0]["rm"], res[1]["rm"])        # buffers were synchronised for validation
     assert len(list((tmp_path / "ck" / "ckpt_main").glob("best_*.pt"))) >= 1
+
+
+def test_bench_runs_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` (ranks started by bench.py itself): the whole control flow of the N > 1 benchmark --
+    DataParallel train steps, barrier + max-over-ranks timing, the per-launch profiling pass (EVERY rank runs its steps: they
+    contain collectives), rank 0's one JSON line -- rehearsed on one card with the gloo backend (AAU_BENCH_BACKEND)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["AAU_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--base_c", "8",
+                        "--size", "128", "--batch", "4"], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["roofline"] is not None and d["cpu_baseline"] is None
