@@ -18,6 +18,9 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
+#ifndef AAU_FILL_AUX
+#define AAU_FILL_AUX 0      // cache policy of the activation fills (2 = nt: measured)
+#endif
 #include "c3args.h"
 
 namespace aau {
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
         unsigned char* dstp = real ? dsm + rr * ROWB + sub * 1024 : dsm + R * ROWB;
         const unsigned soff = row_ok ? (unsigned)(((in_ * d.H + y) * d.W) * d.src_pitch * 2) : 0u;
         const unsigned v = (row_ok && !(abl & 2)) ? ivec : OOB;       // abl: timing ablations (AAU_C3S_ABL), never set in production
-        if (!(abl & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, 0);
+        if (!(abl & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, AAU_FILL_AUX);
     };
     auto issue_end = [&]() {
         irb += PR; if (irb >= R) irb -= R;
