@@ -66,6 +66,7 @@ _SIGS = {
     "aau_conv_split_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_wgrad_ws_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int64)],
     "aau_conv_wgrad_group_ok": [C.POINTER(ConvDesc), I],
+    "aau_conv_wgrad_group_member_ok": [C.POINTER(ConvDesc)],
     "aau_conv_wgrad_group": [C.POINTER(ConvDesc), P, P, P, I, P],
     "aau_conv_igemm_group_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_igemm_group_ws_bytes": [C.POINTER(ConvDesc), I],

@@ -278,6 +278,11 @@ static bool wl_ok(const aau_conv_desc* d) {
     return M >= 1024 && M * d->dst_pitch * 2 < 0x7fffffff && (int64_t)d->N * d->H * d->W * d->src_pitch * 2 < 0x7fffffff;
 }
 
+// 1 when this problem may be a MEMBER of a grouped launch (the group as a whole is judged by aau_conv_wgrad_group_ok)
+extern "C" int aau_conv_wgrad_group_member_ok(const aau_conv_desc* d) {
+    return d && !getenv("AAU_NO_WGRAD_GROUP") && wl_ok(d) ? 1 : 0;
+}
+
 extern "C" int aau_conv_wgrad_group_ok(const aau_conv_desc* descs, int n) {
     if (!descs || n < 1 || n > WL_MAXP || getenv("AAU_NO_WGRAD_GROUP")) return 0;
     int64_t tiles = 0;

@@ -713,6 +713,7 @@ class Plan:
         # gradient of the encoder outputs: its own buffer behind a gate, the lower half of dcat otherwise
         dskip = [None if gate_kinds[lv] is None else self.new(Ms[lv], Cs[lv]) for lv in range(4)]
         dskip_p = [cat_p[lv] if gate_kinds[lv] is None else Cs[lv] for lv in range(4)]
+        pre_wg = []                          # weight gradients deferred into the bridge's grouped launch
         for blk in reversed(dec):            # u1, u2, u3, u4
             lv, Co, Mo, ho, wo, hi, wi = blk["lv"], blk["Co"], blk["Mo"], blk["ho"], blk["wo"], blk["hi"], blk["wi"]
             dya = self.new(Mo, Co)
@@ -780,8 +781,13 @@ class Plan:
             ov = eng.overlap_wgrad
             if ov:
                 b.fork()        # dcat[:, Co:] is final (gate data-gradient accumulated above)
-            b.add_wgrad(ops.conv_desc(B, ho, wo, Co, cat_p[lv], hi, wi, gc, gc, 2, 2, 2, 0, 1), dcat_hi, gsrc, up.dw,
-                        side=ov)
+            upd = ops.conv_desc(B, ho, wo, Co, cat_p[lv], hi, wi, gc, gc, 2, 2, 2, 0, 1)
+            if lv == 3 and aspp and not eng.no_wgrad_group and not ov and ops.conv_wgrad_group_ok([upd], lone_ok=True):
+                # the deepest ConvTranspose2d's weight gradient (32 big tiles over the same 8192 pixels as the bridge's)
+                # rides along in the bridge's grouped launch below instead of half-filling the chip on its own
+                pre_wg.append((upd, dcat_hi, gsrc, up.dw, b.label))
+            else:
+                b.add_wgrad(upd, dcat_hi, gsrc, up.dw, side=ov)
             dg_in = self.new(B * hi * wi, gc)
             b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Co, cat_p[lv], hi, wi, gc, gc, 2, 2, 2, 0, 1, up.cpad_d),
                   dcat_hi, up.pk_d, dg_in, None, None, None, None)
@@ -793,7 +799,7 @@ class Plan:
             dcat5 = self.new(M5, ncat)
             # the weight gradients of the projection and of the spatial branches go into ONE grouped launch
             # (aau_conv_wgrad_group) once every branch's dz exists; their data gradients run as before
-            wg = [] if not eng.no_wgrad_group else None
+            wg = list(pre_wg) if not eng.no_wgrad_group else None
             # ... and the branches' data gradients, which all add into dL/dx of the bridge input, into ONE grouped
             # launch as well (aau_conv_igemm_group): the sum stays in registers across the branches
             dg = []

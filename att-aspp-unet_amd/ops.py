@@ -133,8 +133,11 @@ def wgrad_group_args(descs, srcs, dzs, dws):
     return da, sa, za, wa, n
 
 
-def conv_wgrad_group_ok(descs) -> bool:
+def conv_wgrad_group_ok(descs, lone_ok: bool = False) -> bool:
+    """``lone_ok``: may this ONE problem join a grouped launch (the whole group is checked again where it is emitted)."""
     n = len(descs)
+    if lone_ok:
+        return n == 1 and bool(fn("aau_conv_wgrad_group_member_ok")(C.byref(descs[0])))
     return bool(fn("aau_conv_wgrad_group_ok")((ConvDesc * n)(*descs), n))
 
 

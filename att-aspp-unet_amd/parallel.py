@@ -25,8 +25,9 @@ import torch.distributed as dist
 # mark fired by the engine after the backward of a block -> parameter-name prefixes whose grads are then final
 BUCKET_PLAN = (
     ("u3", ("u3.", "u2.", "u1.", "out_conv.")),
-    ("u4", ("u4.",)),
-    ("bridge", ("bridge.",)),
+    ("u4", ("u4.att.", "u4.conv.")),
+    # u4.up's weight gradient is computed inside the bridge's grouped launch (engine.py: pre_wg), so it belongs to this bucket
+    ("bridge", ("bridge.", "u4.up.")),
     ("d4", ("d4.",)),                      # 8 MB at base_c 48: reduced under the backward of d3..d1
     ("d1", ("d1.", "d2.", "d3.")),         # the only bucket nothing can hide: 2.6 MB
 )

@@ -158,6 +158,7 @@ int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes);
 /* 1x1/stride-1 conv or have Wo % 32 == 0 (K-steps are 32-pixel row segments; steps whose source row is  */
 /* outside the image are skipped); aau_conv_wgrad_group_ok says whether the group is in range AND large   */
 /* enough to fill the chip (otherwise use aau_conv_wgrad per problem).                                  */
+int aau_conv_wgrad_group_member_ok(const aau_conv_desc* d);   /* one problem's eligibility (the group needs >= 160 tiles in all) */
 int aau_conv_wgrad_group_ok(const aau_conv_desc* descs, int n);
 int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* const* srcs,
                          const aau_bf16* const* dzs, float* const* dws, int n, void* stream);
