@@ -87,6 +87,9 @@ _SIGS = {
     "aau_conv1_bn_bwd_reduce": [P, P, P, I, P, P, P, P, P, I, I, I, I, P, P],
     "aau_gap_fwd": [P, I, P, P, I, I, I, P],
     "aau_gap_bwd": [P, P, I, I, I, I, P],
+    "aau_poolbranch_fwd": [P, I, P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, P],
+    "aau_poolbranch_bwd": [P, I, P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "aau_poolbranch_dx": [P, P, I, P, I, I, I, I, P],
     "aau_spatial_sum": [P, I, P, P, I, I, I, P],
     "aau_gate_psi": [P, P, P, P, P, P, P, P, P, L, L, I, P],
     "aau_gate_apply": [P, I, P, P, P, P, P, I, L, I, P],
@@ -96,6 +99,7 @@ _SIGS = {
     "aau_gate2_fwd": [P, P, P, P, P, I, P, P, I, L, I, I, P],
     "aau_gate2_bwd": [P, I, P, I, P, P, P, P, P, I, P, P, P, P, L, I, I, P],
     "aau_fold_stats": [P, L, I, I, I, I, P, P],
+    "aau_fold_stats_pair": [P, L, I, I, P, L, I, I, I, P, P],
     "aau_stats_to_f64": [P, L, I, P, P],
     "aau_outconv_fwd": [P, I, P, P, P, L, I, P],
     "aau_outconv_bwd": [P, I, P, P, P, I, P, P, P, L, I, P],

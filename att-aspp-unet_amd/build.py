@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libaau.so")
-SOURCES = ["runtime.hip", "igemm.hip", "igemm_group.hip", "conv3x3.hip", "conv3x3s.hip", "wgrad.hip", "wgrad3x3.hip", "wgradL.hip", "wgrad3x3r.hip", "bn.hip", "pointwise.hip", "gate.hip", "loss.hip", "optim.hip", "imgproc.hip", "augment.hip"]
+SOURCES = ["runtime.hip", "igemm.hip", "igemm_group.hip", "conv3x3.hip", "conv3x3s.hip", "wgrad.hip", "wgrad3x3.hip", "wgradL.hip", "wgrad3x3r.hip", "bn.hip", "pointwise.hip", "poolbranch.hip", "gate.hip", "loss.hip", "optim.hip", "imgproc.hip", "augment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
          "-Wno-unused-result", "-Wno-unused-value"]
 

@@ -716,6 +716,31 @@ __global__ void fold_stats_kernel(const long long* stats, int C, int which, int 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] += (float)stat_total(stats, C, which, c_begin + i);
 }
+// out[i] += total of statistic 0 of channel cA + i of buffer A (+ of channel cB + i of buffer B): 32 lanes per channel, one
+// replica each, exact integer limb sums through shuffles (the same value as stat_total, a quarter of its dependent loads)
+__global__ __launch_bounds__(256) void fold_stats_pair_kernel(const long long* A, int CA, int cA, const long long* Bs, int CB, int cB,
+                                                               int n, float* out) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+    long long hi = 0, lo = 0;
+    bool poison = false;
+    if (i < n) {
+        const long long* s = A + (((size_t)r * 2 + 0) * CA + cA + i) * 2;
+        hi = s[0]; lo = s[1];
+        poison = A[(size_t)AAU_STAT_REPLICAS * 2 * CA * 2] != 0;
+        if (Bs) {
+            const long long* t = Bs + (((size_t)r * 2 + 0) * CB + cB + i) * 2;
+            hi += t[0]; lo += t[1];
+            poison |= Bs[(size_t)AAU_STAT_REPLICAS * 2 * CB * 2] != 0;
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); }
+    if (i < n && r == 0) {
+        const double v = poison ? __longlong_as_double(0x7ff8000000000000ll)
+                                : (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 4503599627370496.0);
+        out[i] += (float)v;
+    }
+}
 __global__ void stats_to_f64_kernel(const long long* stats, int C, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 2 * C) out[i] = stat_total(stats, C, i / C, i % C);
@@ -730,6 +755,17 @@ extern "C" int aau_fold_stats(const aau_stat* stats, int64_t stats_bytes, int C,
     hipLaunchKernelGGL(fold_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const long long*)stats, C,
                        which, c_begin, n, out);
     return check_launch("aau_fold_stats");
+}
+extern "C" int aau_fold_stats_pair(const aau_stat* a, int64_t a_bytes, int CA, int ca_begin, const aau_stat* b, int64_t b_bytes, int CB,
+                                   int cb_begin, int n, float* out, void* stream) {
+    AAU_REQUIRE(a && out && CA > 0 && ca_begin >= 0 && n > 0 && ca_begin + n <= CA, "aau_fold_stats_pair: bad args (A)");
+    AAU_REQUIRE(!b || (CB > 0 && cb_begin >= 0 && cb_begin + n <= CB), "aau_fold_stats_pair: bad args (B)");
+    AAU_CHECK_STAT("aau_fold_stats_pair", a, a_bytes, CA);
+    AAU_CHECK_STAT("aau_fold_stats_pair", b, b_bytes, b ? CB : 1);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(fold_stats_pair_kernel, dim3((n + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const long long*)a, CA, ca_begin,
+                       (const long long*)b, CB, cb_begin, n, out);
+    return check_launch("aau_fold_stats_pair");
 }
 // out fp32 [2][C] = the totals of an aau_stat buffer (the `red` operand of the BatchNorm-backward apply passes)
 static __global__ void stats_to_f32_kernel(const long long* stats, int C, float* out) {

@@ -617,8 +617,19 @@ class Plan:
             gap_ws = self.new(ops.GAP_WS_ROWS, B, max(Cs[3], Cb), dtype=F32)     # one row per pixel slab
             f.label = "bridge.pool"
             f.add("aau_gap_fwd", p4, Cs[3], pooled, gap_ws, B, h5 * w5, Cs[3])
-            rpool = self.cbr_fwd("bridge.pool.1", "bridge.pool.2", pooled, Cs[3], B, 1, 1, cat5[:, nbr * Cb:], ncat,
-                                 bcast_hw=h5 * w5)
+            if tr and B <= 16 and not eng.no_poolbranch:
+                # training: conv + BatchNorm statistics over the B samples in one latency-sized launch (poolbranch.hip)
+                cvp, bnp = st.convs["bridge.pool.1"], st.bns["bridge.pool.2"]
+                wp = self.bnbuf(Cb)
+                zp_ = self.new(B, Cb)
+                f.add("aau_poolbranch_fwd", pooled, Cs[3], cvp.pk_f, cvp.cpad_f, zp_, bnp.gamma, bnp.beta, bnp.rm, bnp.rv,
+                      bnp.nbt, wp["scale"], wp["shift"], wp["mean"], wp["invstd"], B, Cs[3], Cb, 1e-5, 0.1)
+                f.add("aau_bn_act", zp_, Cb, cat5[:, nbr * Cb:], ncat, wp["scale"], wp["shift"], M5, Cb, 1, h5 * w5, 0.0,
+                      self.drop_seed)
+                rpool = dict(cv=cvp, bn=bnp, w=wp, z=zp_, src=pooled, fused=True)
+            else:
+                rpool = self.cbr_fwd("bridge.pool.1", "bridge.pool.2", pooled, Cs[3], B, 1, 1, cat5[:, nbr * Cb:], ncat,
+                                     bcast_hw=h5 * w5)
             rproj = self.cbr_fwd("bridge.project.0", "bridge.project.1", cat5, ncat, B, h5, w5, bout, Cb, drop=True)
         else:
             rplain = self.cbr_fwd("bridge.0.block.0", "bridge.0.block.1", p4, Cs[3], B, h5, w5, bout, Cb, drop=True)
@@ -775,9 +786,10 @@ class Plan:
             if sA is None:
                 b.add("aau_colsum", dcat_hi, cat_p[lv], up.dbias, rep_ws, Mo, Co)
             else:
-                b.add("aau_fold_stats", sA, 2 * Co, 0, Co, Co, up.dbias)      # channel sums of dcat[:, Co:]
-                if gt is not None:
-                    b.add("aau_fold_stats", sB, Co, 0, 0, Co, up.dbias)
+                # channel sums of dcat[:, Co:] (+ what the gate's data gradient added to it): one launch for both
+                sb_ = sB if gt is not None else None
+                b.add("aau_fold_stats_pair", sA, ops.stat_words(2 * Co) * 8, 2 * Co, Co, sb_, ops.stat_words(Co) * 8 if sb_ is not None else 0,
+                      Co, 0, Co, up.dbias)
             ov = eng.overlap_wgrad
             if ov:
                 b.fork()        # dcat[:, Co:] is final (gate data-gradient accumulated above)
@@ -836,9 +848,16 @@ class Plan:
             b.label = "bridge.pool"
             b.add("aau_spatial_sum", dcat5[:, nbr * Cb:], ncat, dpb, gap_ws, B, h5 * w5, Cb)
             dpooled = self.new(B, Cs[3])
-            rpool_b = dict(rpool)
-            rpool_b["bcast_hw"] = 0
-            self.cbr_bwd(rpool_b, dpb, Cb, din=dpooled, dinp=Cs[3])
+            if rpool.get("fused"):
+                cvp, bnp, wp = rpool["cv"], rpool["bn"], rpool["w"]
+                dzp = self.new(B, Cb)
+                b.add("aau_poolbranch_bwd", dpb, Cb, rpool["z"], rpool["src"], Cs[3], bnp.gamma, wp["scale"], wp["shift"],
+                      wp["mean"], wp["invstd"], dzp, bnp.dgamma, bnp.dbeta, cvp.dw, B, Cs[3], Cb)
+                b.add("aau_poolbranch_dx", dzp, cvp.pk_d, cvp.cpad_d, dpooled, Cs[3], B, Cs[3], Cb)
+            else:
+                rpool_b = dict(rpool)
+                rpool_b["bcast_hw"] = 0
+                self.cbr_bwd(rpool_b, dpb, Cb, din=dpooled, dinp=Cs[3])
             b.label = "bridge.pool"
             b.add("aau_gap_bwd", dpooled, dp4, Cs[3], B, h5 * w5, Cs[3])
         else:
@@ -926,6 +945,7 @@ class Engine:
         # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
         # reading the routed gradient the reduce pass stored
         self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"
+        self.no_poolbranch = os.environ.get("AAU_NO_POOLBRANCH", "0") == "1"   # A/B: the generic launches for bridge.pool
         # z of the first layer recomputed from the frame instead of stored (-201 MB of HBM at bs 8 / 512^2): measured
         # 0.08 ms SLOWER per step (the three recomputing kernels are VALU / latency bound, not byte bound), so opt-in
         self.no_recompute_z1 = os.environ.get("AAU_RECOMPUTE_Z1", "0") != "1" or self.no_fuse_conv1

@@ -311,6 +311,22 @@ def gap_bwd(dpooled, dx, dxp, N, HW, Cc):
     check(fn("aau_gap_bwd")(_p(dpooled), _p(dx), dxp, N, HW, Cc, _stream()), "aau_gap_bwd")
 
 
+def poolbranch_fwd(x, xp, wpk, cpad, z, gamma, beta, rm, rv, nbt, scale, shift, mean, invstd, B, Cin, Cout, eps=1e-5,
+                   momentum=0.1):
+    """Image-pool branch, conv + BatchNorm statistics over the batch (aau.h: aau_poolbranch_fwd)."""
+    check(fn("aau_poolbranch_fwd")(_p(x), xp, _p(wpk), cpad, _p(z), _p(gamma), _p(beta), _p(rm), _p(rv), _p(nbt), _p(scale),
+                                   _p(shift), _p(mean), _p(invstd), B, Cin, Cout, eps, momentum, _stream()), "aau_poolbranch_fwd")
+
+
+def poolbranch_bwd(dy, dyp, z, x, xp, gamma, scale, shift, mean, invstd, dz, dgamma, dbeta, dw, B, Cin, Cout):
+    check(fn("aau_poolbranch_bwd")(_p(dy), dyp, _p(z), _p(x), xp, _p(gamma), _p(scale), _p(shift), _p(mean), _p(invstd), _p(dz),
+                                   _p(dgamma), _p(dbeta), _p(dw), B, Cin, Cout, _stream()), "aau_poolbranch_bwd")
+
+
+def poolbranch_dx(dz, wpd, cpad_d, dx, dxp, B, Cin, Cout):
+    check(fn("aau_poolbranch_dx")(_p(dz), _p(wpd), cpad_d, _p(dx), dxp, B, Cin, Cout, _stream()), "aau_poolbranch_dx")
+
+
 def spatial_sum(src, sp, out, ws, N, HW, Cc):
     _check_gap_ws(ws, N, Cc, "spatial_sum")
     check(fn("aau_spatial_sum")(_p(src), sp, _p(out), _p(ws), N, HW, Cc, _stream()), "aau_spatial_sum")

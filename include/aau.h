@@ -301,6 +301,23 @@ int aau_gap_bwd(const aau_bf16* dpooled, aau_bf16* dx, int dx_pitch, int N, int 
 /* out[n][c] = sum_p src[n][p][c]   (bf16 in, bf16 out, fp32 accumulate)                  */
 int aau_spatial_sum(const aau_bf16* src, int src_pitch, aau_bf16* out, float* ws, int N, int HW, int C, void* stream);
 
+/* The image-pool branch between its spatial ends (pipeline:75-77): pooled [B][Cin] -> Conv2d(Cin, Cout, 1, bias=False) */
+/* -> BatchNorm2d over the B samples (training) -> ReLU, as three latency-sized launches (csrc/poolbranch.hip) instead of   */
+/* the generic conv / finalize / reduce / apply / wgrad / dgrad sequence.  B <= 16, Cin and Cout multiples of 8.          */
+/* fwd: z[b][q] = bf16(sum_c x[b][c] wpk[q][c]); batch statistics of the fp32 sums with aau_bn_finalize's arithmetic.     */
+/* bwd: g = dy * [z*scale+shift > 0]; dbeta += sum g; dgamma += sum g zhat; dz = bf16(gamma invstd (g - mean g -       */
+/*      zhat mean(g zhat))); dw[q][c] += sum_b dz[b][q] x[b][c].   dx: dx[b][c] = bf16(sum_q dz[b][q] wpd[c][q]).        */
+int aau_poolbranch_fwd(const aau_bf16* x, int x_pitch, const aau_bf16* wpk, int Cpad, aau_bf16* z, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                       float* scale, float* shift, float* save_mean, float* save_invstd, int B, int Cin, int Cout,
+                       float eps, float momentum, void* stream);
+int aau_poolbranch_bwd(const aau_bf16* dy, int dy_pitch, const aau_bf16* z, const aau_bf16* x, int x_pitch,
+                       const float* gamma, const float* scale, const float* shift, const float* save_mean,
+                       const float* save_invstd, aau_bf16* dz, float* dgamma, float* dbeta, float* dw, int B, int Cin,
+                       int Cout, void* stream);
+int aau_poolbranch_dx(const aau_bf16* dz, const aau_bf16* wpd, int Cpad_d, aau_bf16* dx, int dx_pitch, int B, int Cin,
+                      int Cout, void* stream);
+
 /* ---- attention gate (pipeline:85-92) -------------------------------------------------- */
 /* psi_pre[m] = sum_f wpsi[f]*relu(zg[m,f]*sg[f]+hg[f] + zx[m,f]*sx[f]+hx[f]); also sum /   */
 /* sumsq of psi_pre into stats [REPLICAS][2][1].                                           */
@@ -374,6 +391,10 @@ int aau_fold_replicas(const float* ws, int stride, float* out, int n, void* stre
 /* out[i] += total of statistic `which` (0 sum, 1 sum of squares) of channel c_begin + i of an aau_stat buffer   */
 /* for C channels (e.g. the ConvTranspose2d bias gradient = channel sums that a data-gradient conv accumulated) */
 int aau_fold_stats(const aau_stat* stats, int64_t stats_bytes, int C, int which, int c_begin, int n, float* out, void* stream);
+/* out[i] += sum-statistic of channel ca_begin + i of buffer a (+ of channel cb_begin + i of buffer b, b may be NULL): the   */
+/* ConvTranspose2d bias gradient of a gated decoder level has two contributions (the conv and the gate data gradients)     */
+int aau_fold_stats_pair(const aau_stat* a, int64_t a_bytes, int CA, int ca_begin, const aau_stat* b, int64_t b_bytes,
+                        int CB, int cb_begin, int n, float* out, void* stream);
 /* out fp64 [2][C] = the totals of an aau_stat buffer (NaN if poisoned by a non-finite partial)                   */
 int aau_stats_to_f64(const aau_stat* stats, int64_t stats_bytes, int C, double* out, void* stream);
 

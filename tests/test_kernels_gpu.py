@@ -738,3 +738,82 @@ def test_strip_data_gradient_with_fused_batchnorm_backward_sums(ops):
     ops.conv_igemm_bnred(dd, dzd, wd, out, z, C_, dev(scale), dev(shift), dev(mean), dev(invstd), sums2)
     torch.cuda.synchronize()
     assert torch.equal(sums, sums2)
+
+
+@pytest.mark.parametrize("case", [(8, 384, 768), (2, 64, 128), (16, 40, 24), (3, 8, 8)])
+def test_image_pool_branch_kernels(ops, case):
+    """aau_poolbranch_fwd / _bwd / _dx against torch autograd of Conv2d(Cin, Cout, 1, bias=False) -> BatchNorm2d (training)
+    -> ReLU on [B, Cin, 1, 1] (pipeline:75-77) in fp32 from the same bf16-rounded operands."""
+    B, Cin, Cout = case
+    g = torch.Generator().manual_seed(5 + B)
+    x = R.bf16_round(torch.randn(B, Cin, generator=g))
+    w = R.bf16_round(torch.randn(Cout, Cin, generator=g) / Cin ** 0.5)
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    dy = R.bf16_round(torch.randn(B, Cout, generator=g))
+    rm0, rv0 = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+    # reference
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    zr = xr @ wr.t()
+    yr = torch.relu(torch.nn.functional.batch_norm(zr, rm, rv, gr, br, True, 0.1, 1e-5))
+    yr.backward(dy)
+    cpf, cpd = ops.cpad_of(Cin), ops.cpad_of(Cout)
+    xp = Cin + 8                                               # a pitch
+    xd = torch.zeros(B, xp, dtype=torch.bfloat16, device="cuda")
+    xd[:, :Cin] = x.to(torch.bfloat16).cuda()
+    wf = dev(pack_fwd(w[:, :, None, None], cpf))
+    wd = dev(pack_dgrad(w[:, :, None, None], cpd))
+    z = torch.empty(B, Cout, dtype=torch.bfloat16, device="cuda")
+    f32 = lambda *s: torch.zeros(*s, device="cuda")
+    scale, shift, mean, invstd = f32(Cout), f32(Cout), f32(Cout), f32(Cout)
+    rmd, rvd, nbt = dev(rm0.clone()), dev(rv0.clone()), torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.poolbranch_fwd(xd, xp, wf, cpf, z, dev(gamma), dev(beta), rmd, rvd, nbt, scale, shift, mean, invstd, B, Cin, Cout)
+    torch.cuda.synchronize()
+    assert int(nbt) == 1
+    assert rel_err(z.cpu(), zr.detach()) < 6e-3
+    assert float((mean.cpu() - zr.detach().mean(0)).abs().max()) < 1e-4
+    var = zr.detach().var(0, unbiased=False)
+    assert float((invstd.cpu() - 1 / torch.sqrt(var + 1e-5)).abs().max()) < 2e-3 * float((1 / torch.sqrt(var + 1e-5)).max())
+    assert float((rmd.cpu() - rm).abs().max()) < 1e-4 and float((rvd.cpu() - rv).abs().max()) < 1e-3
+    y = torch.relu(z.float() * scale + shift).cpu()
+    # z is stored in bf16: its rounding reaches y multiplied by the channel's scale (large where B = 2 values lie close)
+    assert bool(((y - yr.detach()).abs() <= 2.0 ** -8 * (z.float().abs() * scale.abs()).cpu() + 1e-2).all())
+    # backward
+    dz = torch.empty(B, Cout, dtype=torch.bfloat16, device="cuda")
+    dgam, dbet = f32(Cout) + 1.0, f32(Cout) + 2.0             # accumulated into
+    dw = f32(Cout, Cin) + 0.5
+    dyd = torch.zeros(B, Cout + 16, dtype=torch.bfloat16, device="cuda")
+    dyd[:, :Cout] = dy.to(torch.bfloat16).cuda()
+    ops.poolbranch_bwd(dyd, Cout + 16, z, xd, xp, dev(gamma), scale, shift, mean, invstd, dz, dgam, dbet, dw, B, Cin, Cout)
+    dx = torch.full((B, xp), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.poolbranch_dx(dz, wd, cpd, dx, xp, B, Cin, Cout)
+    torch.cuda.synchronize()
+    tol = lambda t: 2e-2 * float(t.abs().max()) + 1e-3
+    # (1) the BatchNorm-backward formulas in fp64 from the kernel's own z and saved statistics
+    zc, sc, sh, mu, isd = (t.cpu().double() for t in (z.float(), scale, shift, mean, invstd))
+    g_ = dy.double() * ((zc.float() * sc.float() + sh.float()) > 0)
+    zh = (zc - mu) * isd
+    s1, s2 = g_.sum(0), (g_ * zh).sum(0)
+    dze = gamma.double() * isd * (g_ - s1 / B - zh * s2 / B)
+    assert float((dbet.cpu() - 2.0 - s1).abs().max()) < 1e-4 * float(s1.abs().max()) + 1e-5
+    assert float((dgam.cpu() - 1.0 - s2).abs().max()) < 1e-4 * float(s2.abs().max()) + 1e-5
+    assert float((dz.float().cpu() - dze).abs().max()) < 2.0 ** -7 * float(dze.abs().max()) + 1e-6
+    dwe = dz.float().cpu().double().t() @ x.double()
+    assert float((dw.cpu() - 0.5 - dwe).abs().max()) < 1e-4 * float(dwe.abs().max()) + 1e-5
+    # (2) torch autograd in fp32 (B >= 8: with fewer samples the rounding of z moves zhat by O(1) in channels whose
+    # values lie close together); masks can differ where y is within rounding of zero: channels whose mask agrees
+    if B >= 8:
+        okc = (((z.float() * scale + shift).cpu() > 0) == (yr.detach() > 0)).all(0)
+        assert okc.float().mean() > 0.9
+        assert float(((dbet.cpu() - 2.0) - br.grad)[okc].abs().max()) < tol(br.grad)
+        assert float(((dgam.cpu() - 1.0) - gr.grad)[okc].abs().max()) < tol(gr.grad)
+        assert float(((dw.cpu() - 0.5) - wr.grad)[okc].abs().max()) < tol(wr.grad)
+        if bool(okc.all()):
+            assert float((dx[:, :Cin].float().cpu() - xr.grad).abs().max()) < tol(xr.grad)
+    assert float(dx[:, Cin:].float().min()) == 7.0            # the pitch tail is not written
+    # dx from the kernel's own dz, exactly
+    dxe = dz.float().cpu() @ w
+    assert float((dx[:, :Cin].float().cpu() - dxe).abs().max()) < 1e-2 * float(dxe.abs().max()) + 1e-4
+    with pytest.raises(RuntimeError):
+        ops.poolbranch_dx(dz, wd, cpd, dx, xp, 17, Cin, Cout)
