@@ -819,6 +819,26 @@ class Plan:
             for i, r in enumerate(br):
                 self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0, defer_wgrad=wg,
                              defer_dgrad=dg)
+            # The grouped weight gradient is latency-bound (one or two workgroups per CU, each waiting ~2 us for its next
+            # K-step: scripts/probes/wl_sched.py) and nothing needs its result before the gradient bucket closes.  Opt-in
+            # (AAU_BRIDGE_WG_SIDE=1): on the side stream beside the grouped data gradient and the image-pool branch --
+            # measured +0.14 ms on the step (same-box A/B, 3 pairs), like every other two-stream form tried on this chip.
+            wg_side = False
+            if wg:
+                descs = [w_[0] for w_ in wg]
+                b.label = "bridge(grouped)"
+                if len(wg) <= 8 and ops.conv_wgrad_group_ok(descs):
+                    pack = ops.wgrad_group_args(descs, [w_[1] for w_ in wg], [w_[2] for w_ in wg], [w_[3] for w_ in wg])
+                    b.keep.extend([w_[k] for w_ in wg for k in (1, 2, 3)])
+                    b.keep.append(pack)
+                    wg_side = eng.bridge_wg_side
+                    if wg_side:
+                        b.fork()
+                    b.add("aau_conv_wgrad_group", *pack, side=wg_side)
+                else:
+                    for dwd, src, dz_, dw_, lab in wg:
+                        b.label = lab
+                        b.add_wgrad(dwd, src, dz_, dw_)
             dgd = [g_[0] for g_ in dg]
             if len(dg) >= 2 and ops.conv_igemm_group_ok(dgd):
                 b.label = "bridge(grouped)"
@@ -832,18 +852,6 @@ class Plan:
                 for dd_, dz_, pk_, din_, lab in dg:
                     b.label = lab
                     b.add("aau_conv_igemm", dd_, dz_, pk_, din_, None, None, None, None)
-            if wg:
-                descs = [w_[0] for w_ in wg]
-                b.label = "bridge(grouped)"
-                if len(wg) <= 8 and ops.conv_wgrad_group_ok(descs):
-                    pack = ops.wgrad_group_args(descs, [w_[1] for w_ in wg], [w_[2] for w_ in wg], [w_[3] for w_ in wg])
-                    b.keep.extend([w_[k] for w_ in wg for k in (1, 2, 3)])
-                    b.keep.append(pack)
-                    b.add("aau_conv_wgrad_group", *pack)
-                else:
-                    for dwd, src, dz_, dw_, lab in wg:
-                        b.label = lab
-                        b.add_wgrad(dwd, src, dz_, dw_)
             dpb = self.new(B, Cb)
             b.label = "bridge.pool"
             b.add("aau_spatial_sum", dcat5[:, nbr * Cb:], ncat, dpb, gap_ws, B, h5 * w5, Cb)
@@ -860,6 +868,8 @@ class Plan:
                 self.cbr_bwd(rpool_b, dpb, Cb, din=dpooled, dinp=Cs[3])
             b.label = "bridge.pool"
             b.add("aau_gap_bwd", dpooled, dp4, Cs[3], B, h5 * w5, Cs[3])
+            if wg_side:
+                b.join()
         else:
             self.cbr_bwd(rplain, dy, Cb, din=dp4, dinp=Cs[3])
         mark("bridge")
@@ -945,6 +955,7 @@ class Engine:
         # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
         # reading the routed gradient the reduce pass stored
         self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"
+        self.bridge_wg_side = os.environ.get("AAU_BRIDGE_WG_SIDE", "0") == "1"   # opt-in, measured negative
         self.no_poolbranch = os.environ.get("AAU_NO_POOLBRANCH", "0") == "1"   # A/B: the generic launches for bridge.pool
         # z of the first layer recomputed from the frame instead of stored (-201 MB of HBM at bs 8 / 512^2): measured
         # 0.08 ms SLOWER per step (the three recomputing kernels are VALU / latency bound, not byte bound), so opt-in
