@@ -18,6 +18,11 @@
 // projection convs (:71-78), the gate 1x1 convs (:88-89), ConvTranspose2d(2,2) (:101,
 // as a GEMM with N = 4*Co and a pixel-shuffle store) and their input gradients.
 #include "common.h"
+#ifdef AAU_NO_MFMA_PIN         /* A/B build (build.py -DAAU_NO_MFMA_PIN --tag=nopin): the scheduler's own order */
+#define AAU_PIN_SB()
+#else
+#define AAU_PIN_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
 #include <type_traits>
 
 namespace aau {
@@ -249,6 +254,10 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
         // DMA instructions were issued in a burst or between the MFMAs.  Through registers the data returns on the
         // vector-memory path and enters LDS at 128 B/clk, beside the ds_read traffic.
         constexpr int NL = NA + NW;
+#ifndef AAU_WIDE_MPW
+#define AAU_WIDE_MPW 2
+#endif
+        constexpr int WIDE_MPW = AAU_WIDE_MPW;      // MFMAs of the first group in front of each LDS write
         static_assert(BQ % (NWV * RPI) == 0, "uniform load count per step");
         const int nsteps = __builtin_popcount(tapmask) * a.nchunk;
         u32x4 R0[NL], R1[NL];
@@ -313,9 +322,22 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
             read_frags(t & 1, 1, F1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (decltype(fetch)::value) gload(Rfree);
+            AAU_PIN_SB();
             mma(F0);
             if constexpr (decltype(write)::value) {
                 lwrite((t + 1) & 1, Rnext);
+                // Left alone, the scheduler sinks ten of the twelve MFMAs of this group BELOW the barrier (they are pure
+                // register operations): the wait for the fetched step, its five ds_write_b128, the wait for them and the
+                // barrier then run with the matrix pipe idle, every step.  Two MFMAs, one write, five times, two MFMAs:
+#ifndef AAU_NO_MFMA_PIN      /* A/B build: the scheduler's own order */
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, WIDE_MPW, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // DS write
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NI * MI - NL * WIDE_MPW, 0);
+#endif
+                AAU_PIN_SB();
                 __syncthreads();
                 read_frags((t + 1) & 1, 0, F0);
                 __builtin_amdgcn_sched_barrier(0);

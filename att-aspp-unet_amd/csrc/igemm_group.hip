@@ -13,6 +13,11 @@
 // The main loop is the wide tile of igemm.hip (128 pixels x 192 channels, 8 waves, register-staged fill, fragments read
 // one sub-step ahead); what is new is the cursor (segment, tap, chunk).
 #include "common.h"
+#ifdef AAU_NO_MFMA_PIN         /* A/B build (build.py -DAAU_NO_MFMA_PIN --tag=nopin): the scheduler's own order */
+#define AAU_PIN_SB()
+#else
+#define AAU_PIN_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
 #include <type_traits>
 
 namespace aau {
@@ -219,9 +224,21 @@ __global__ __launch_bounds__(512) void igemm_group_kernel(const GroupArgs a) {
             read_frags(t & 1, 1, F1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (decltype(fetch)::value) gload(Rfree);
+            AAU_PIN_SB();
             mma(F0);
             if constexpr (decltype(write)::value) {
                 lwrite((t + 1) & 1, Rnext);
+                // keep this group's MFMAs ABOVE the barrier, two in front of every LDS write (igemm.hip: left alone the
+                // scheduler sinks them below it and the write / wait / barrier run with the matrix pipe idle)
+#ifndef AAU_NO_MFMA_PIN      /* A/B build: the scheduler's own order */
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NI * MI - NL * 2, 0);
+#endif
+                AAU_PIN_SB();
                 __syncthreads();
                 read_frags((t + 1) & 1, 0, F0);
                 __builtin_amdgcn_sched_barrier(0);
