@@ -77,6 +77,10 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
     constexpr int WPX = MI * 16;
     constexpr int KSUB = BK / 32;
 
+#ifdef AAU_IGEMM_STAMP
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+    unsigned long long st_loop1 = 0;
+#endif
     __shared__ __attribute__((aligned(16))) unsigned short ssmem[(BQ == 192) ? 8 : 2 * (BQ + BP) * BK];
     extern __shared__ __attribute__((aligned(16))) unsigned short dsmem[];
     unsigned short* const smem = (BQ == 192) ? dsmem : ssmem;
@@ -168,7 +172,10 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
         __shared__ unsigned s_mask;
         if (tid == 0) s_mask = 0;
         __syncthreads();
-        if (mine) atomicOr(&s_mask, mine);
+        // one LDS atomic per WAVE: 512 lanes adding to the same word serialise (the stamps put 4.5 us of a 7.4-us prologue here)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor(mine, o, 64);
+        if (lane == 0 && mine) atomicOr(&s_mask, mine);
         __syncthreads();
         tapmask = __builtin_amdgcn_readfirstlane(s_mask);
         __syncthreads();
@@ -316,13 +323,36 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
         // The steady state is branch-free (the compiler's vmcnt bookkeeping then waits for the OLDER register set only
         // and leaves the younger fetch in flight); the last two steps run without a fetch.
         Frag F0, F1;
+#ifdef AAU_IGEMM_STAMP
+        // diagnostic build only (build.py -DAAU_IGEMM_STAMP --tag=stamp; scripts/probes/igemm_stamp.py): s_memtime at the three
+        // points of an iteration where the LDS counter is (nearly) drained anyway; phase sums per wave -> a.shift (scale null)
+        unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_last = 0;
+        auto stamp = [&]() -> unsigned long long {
+            unsigned long long v;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+            return v;
+        };
+#define AAU_ST(acc)                                          \
+        {                                                    \
+            const unsigned long long now_ = stamp();         \
+            acc += now_ - st_last;                           \
+            st_last = now_;                                  \
+        }
+#else
+#define AAU_ST(acc)
+#endif
         auto iter = [&](int t, u32x4 (&Rnext)[NL], u32x4 (&Rfree)[NL], auto fetch, auto write) {
             // sched_barrier: the reads must ISSUE ahead of the MFMAs they hide behind (left alone, the scheduler sinks
             // them to just before their first use, one sub-step later)
+            AAU_ST(st_b)                          // since the barrier: first fragment reads of this step + second MFMA group
             read_frags(t & 1, 1, F1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (decltype(fetch)::value) gload(Rfree);
             AAU_PIN_SB();
+#ifdef AAU_IGEMM_STAMP2
+            AAU_ST(st_d)                          // (perturbing: drains the fragment reads) top -> fetch issued, fragments landed
+            AAU_PIN_SB();
+#endif
             mma(F0);
             if constexpr (decltype(write)::value) {
                 lwrite((t + 1) & 1, Rnext);
@@ -338,7 +368,9 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
                 __builtin_amdgcn_sched_group_barrier(0x008, NI * MI - NL * WIDE_MPW, 0);
 #endif
                 AAU_PIN_SB();
+                AAU_ST(st_c)                      // since the top: second fragment reads, fetch, first MFMA group + LDS writes
                 __syncthreads();
+                AAU_ST(st_a)                      // wait for the writes + barrier
                 read_frags((t + 1) & 1, 0, F0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -351,6 +383,10 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
         lwrite(0, R0);
         __syncthreads();
         read_frags(0, 0, F0);
+#ifdef AAU_IGEMM_STAMP
+        st_last = stamp();
+        const unsigned long long st_begin = st_last, st_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         int t = 0;
         for (; t + 3 < nsteps; t += 2) {          // steps t+2 and t+3 exist
             iter(t, R1, R0, Y{}, Y{});
@@ -367,6 +403,16 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
         } else {
             iter(t, R1, R0, N{}, N{});
         }
+#ifdef AAU_IGEMM_STAMP
+        if (lane == 0 && a.scale == nullptr && a.shift != nullptr && blockIdx.x < 64) {
+            unsigned long long* dbg = (unsigned long long*)a.shift + ((size_t)blockIdx.x * NWV + wave) * 10;
+            dbg[0] = st_a; dbg[1] = st_b; dbg[2] = st_c; dbg[3] = stamp() - st_begin; dbg[4] = (unsigned long long)nsteps;
+            dbg[5] = __builtin_amdgcn_s_memrealtime() - st_rt0;
+            dbg[6] = st_begin - st_entry;        // prologue
+            dbg[7] = st_d;
+        }
+        st_loop1 = stamp();
+#endif
     } else {
     stage(0, tap, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -562,6 +608,13 @@ __global__ __launch_bounds__((BQ == 192) ? 512 : 256) void igemm_kernel(const Ig
         __syncthreads();
         stats_publish(sst, NWV, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
     }
+#ifdef AAU_IGEMM_STAMP
+    if constexpr (WIDE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && a.scale == nullptr && a.shift != nullptr && blockIdx.x < 64)
+            ((unsigned long long*)a.shift)[((size_t)blockIdx.x * NWV + wave) * 10 + 8] = __builtin_amdgcn_s_memtime() - st_loop1;   // epilogue
+    }
+#endif
 }
 
 // conv3x3.hip
@@ -629,7 +682,9 @@ static int conv_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_
     AAU_REQUIRE((int64_t)d->N * d->H * d->W < 0x7fffffff && (int64_t)d->N * d->Ho * d->Wo < 0x7fffffff,
                 "aau_conv_igemm: pixel count overflows int32");
 #ifndef ABL_STAMP
+#ifndef AAU_IGEMM_STAMP      /* the diagnostic build takes its stamp buffer through `shift` */
     AAU_REQUIRE((scale == nullptr) == (shift == nullptr), "aau_conv_igemm: scale and shift come together");
+#endif
 #endif
     AAU_REQUIRE(!d->shuffle2x2 || (d->Cout % 32 == 0), "aau_conv_igemm: shuffle2x2 needs Cout %% 32 == 0");
     AAU_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)wpk & 15) == 0 && ((uintptr_t)dst & 7) == 0,

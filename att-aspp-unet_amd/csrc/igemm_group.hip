@@ -110,7 +110,9 @@ __global__ __launch_bounds__(512) void igemm_group_kernel(const GroupArgs a) {
             }
             if (any) mine |= 1u << t;
         }
-        if (mine) atomicOr(&s_mask[g], mine);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine |= __shfl_xor(mine, o, 64);      // one LDS atomic per wave (igemm.hip)
+        if (lane == 0 && mine) atomicOr(&s_mask[g], mine);
     }
     __syncthreads();
 
