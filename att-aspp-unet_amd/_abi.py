@@ -68,6 +68,8 @@ _SIGS = {
     "aau_conv_wgrad_group_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_wgrad_group_member_ok": [C.POINTER(ConvDesc)],
     "aau_conv_wgrad_group": [C.POINTER(ConvDesc), P, P, P, I, P],
+    "aau_conv_igemm_multi_ok": [C.POINTER(ConvDesc), I],
+    "aau_conv_igemm_multi": [C.POINTER(ConvDesc), P, P, P, P, P, I, P],
     "aau_conv_igemm_group_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_igemm_group_ws_bytes": [C.POINTER(ConvDesc), I],
     "aau_conv_igemm_group": [C.POINTER(ConvDesc), P, P, I, P, P, P],

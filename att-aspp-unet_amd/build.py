@@ -30,7 +30,7 @@ def source_hash() -> str:
     quotes a profile's traffic figure when it was measured on THESE kernels."""
     import hashlib
     h = hashlib.sha256()
-    for p in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "c3args.h"), os.path.join(ROOT, "include", "aau.h")]):
+    for p in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "c3args.h"), os.path.join(CSRC, "igemm_body.inc"), os.path.join(ROOT, "include", "aau.h")]):
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as f:
             h.update(f.read())
@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = True, defines=(), tag: str = "") 
     lib_out = os.path.join(LIBDIR, f"libaau_{tag}.so") if tag else LIB
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    deps = [os.path.join(ROOT, "include", "aau.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "c3args.h")]
+    deps = [os.path.join(ROOT, "include", "aau.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "c3args.h"), os.path.join(CSRC, "igemm_body.inc")]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -400,7 +400,7 @@ class Plan:
 
     # ---- ConvBNReLU on MFMA: forward ----
     def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0, pool=None, head=None,
-                src_split=(0, 0)):
+                src_split=(0, 0), group=None):
         """conv(cname) -> BN(bname) -> ReLU; returns the per-layer record used by the backward.
         ``head`` (training only): the out_conv ConvP when this is the last ConvBNReLU -- its activation feeds out_conv
         alone, so BN + ReLU + out_conv run as one pass and neither the activation nor its gradient is stored."""
@@ -416,6 +416,21 @@ class Plan:
             z = self.new(M, cv.O)
             d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f,
                               src_split=src_split)
+            if group is not None:
+                # ``group``: the conv joins one multi-problem launch (aau_conv_igemm_multi) emitted by the caller, who then
+                # runs the statistics / activation part recorded here
+                lab = self.fwd.label
+                group["convs"].append((d, src, cv.pk_f, z, w["stats"], lab))
+
+                def post(bn=bn, w=w, z=z, lab=lab):
+                    self.fwd.label = lab
+                    self._bn_finalize(bn, w, M)
+                    self.fwd.add("aau_bn_act", z, cv.O, ydst, yp, w["scale"], w["shift"], M, cv.O, 1, 0,
+                                 self.drop_p if drop else 0.0, self.drop_seed)
+                assert head is None and pool is None and not bcast_hw
+                group["post"].append(post)
+                rec["z"] = z
+                return rec
             self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
             self._bn_finalize(bn, w, M)
             Mo = M * bcast_hw if bcast_hw else M
@@ -611,8 +626,28 @@ class Plan:
             nbr = len(model.bridge.blocks)
             ncat = (nbr + 1) * Cb
             cat5 = self.new(M5, ncat)
+            # training: the spatial branches' convolutions as ONE multi-problem launch where the library serves it (each
+            # of them is one workgroup per CU on its own), longest problem first
+            grp = dict(convs=[], post=[]) if tr and 2 <= nbr <= 4 and not eng.no_igemm_multi else None
             br = [self.cbr_fwd(f"bridge.blocks.{i}.0", f"bridge.blocks.{i}.1", p4, Cs[3], B, h5, w5,
-                               cat5[:, i * Cb:], ncat) for i in range(nbr)]
+                               cat5[:, i * Cb:], ncat, group=grp) for i in range(nbr)]
+            if grp is not None:
+                cvs = grp["convs"]
+                order = sorted(range(len(cvs)), key=lambda i: -(cvs[i][0].KH * cvs[i][0].KW) * 100 + cvs[i][0].dil)
+                descs = [cvs[i][0] for i in order]
+                if ops.conv_igemm_multi_ok(descs):
+                    f.label = "bridge(multi)"
+                    pack = ops.igemm_multi_args(descs, [cvs[i][1] for i in order], [cvs[i][2] for i in order],
+                                                [cvs[i][3] for i in order], [cvs[i][4] for i in order])
+                    f.keep.extend([cvs[i][k] for i in order for k in (1, 2, 3, 4)])
+                    f.keep.append(pack)
+                    f.add("aau_conv_igemm_multi", *pack)
+                else:
+                    for d_, src_, pk_, z_, st_, lab in cvs:
+                        f.label = lab
+                        f.add("aau_conv_igemm", d_, src_, pk_, z_, None, None, None, st_)
+                for post in grp["post"]:
+                    post()
             pooled = self.new(B, Cs[3])
             gap_ws = self.new(ops.GAP_WS_ROWS, B, max(Cs[3], Cb), dtype=F32)     # one row per pixel slab
             f.label = "bridge.pool"
@@ -956,6 +991,7 @@ class Engine:
         # reading the routed gradient the reduce pass stored
         self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"
         self.bridge_wg_side = os.environ.get("AAU_BRIDGE_WG_SIDE", "0") == "1"   # opt-in, measured negative
+        self.no_igemm_multi = os.environ.get("AAU_NO_IGEMM_MULTI", "0") == "1"   # A/B: one launch per ASPP branch
         self.no_poolbranch = os.environ.get("AAU_NO_POOLBRANCH", "0") == "1"   # A/B: the generic launches for bridge.pool
         # z of the first layer recomputed from the frame instead of stored (-201 MB of HBM at bs 8 / 512^2): measured
         # 0.08 ms SLOWER per step (the three recomputing kernels are VALU / latency bound, not byte bound), so opt-in

@@ -156,6 +156,31 @@ def igemm_group_args(descs, srcs, wpks, dst, ws):
     return da, sa, wa, n, dst, ws
 
 
+def igemm_multi_args(descs, srcs, wpks, dsts, stats):
+    """ctypes argument pack of aau_conv_igemm_multi (keep the returned tuple alive while the call may run)."""
+    n = len(descs)
+    da = (ConvDesc * n)(*descs)
+    sa = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    wa = (C.c_void_p * n)(*[t.data_ptr() for t in wpks])
+    oa = (C.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    ta = (C.c_void_p * n)(*[None if t is None else t.data_ptr() for t in stats])
+    ba = (C.c_int64 * n)(*[0 if t is None else t.numel() * t.element_size() for t in stats])
+    return da, sa, wa, oa, ta, ba, n
+
+
+def conv_igemm_multi_ok(descs) -> bool:
+    n = len(descs)
+    return bool(fn("aau_conv_igemm_multi_ok")((ConvDesc * n)(*descs), n))
+
+
+def conv_igemm_multi(descs, srcs, wpks, dsts, stats):
+    """Problem i = conv_igemm(descs[i], srcs[i], wpks[i], dsts[i], stats=stats[i]), all in one launch (see include/aau.h)."""
+    for d, t in zip(descs, stats):
+        _check_stats(t, d.Cout, "conv_igemm_multi")
+    pack = igemm_multi_args(descs, srcs, wpks, dsts, stats)
+    check(fn("aau_conv_igemm_multi")(*pack, _stream()), "aau_conv_igemm_multi")
+
+
 def conv_igemm_group_ok(descs) -> bool:
     n = len(descs)
     return bool(fn("aau_conv_igemm_group_ok")((ConvDesc * n)(*descs), n))

@@ -163,6 +163,15 @@ int aau_conv_wgrad_group_ok(const aau_conv_desc* descs, int n);
 int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* const* srcs,
                          const aau_bf16* const* dzs, float* const* dws, int n, void* stream);
 
+/* Several independent convolutions in ONE launch: problem i is exactly aau_conv_igemm(&descs[i], srcs[i], wpks[i],      */
+/* dsts[i], no bias / affine, stats[i]) -- its own weights, dilation, destination and statistics.  Built for the forward   */
+/* of the four spatial ASPP branches (pipeline:80-83), which are one workgroup per CU each when launched separately.        */
+/* n = 2..4 problems that would each take the 128 x 192 tile (aau_conv_igemm_multi_ok); bitwise the results of the         */
+/* separate launches.  `stats` / `stats_bytes` may be NULL (no statistics) or hold NULL entries.                           */
+int aau_conv_igemm_multi_ok(const aau_conv_desc* descs, int n);
+int aau_conv_igemm_multi(const aau_conv_desc* descs, const aau_bf16* const* srcs, const aau_bf16* const* wpks,
+                         aau_bf16* const* dsts, aau_stat* const* stats, const int64_t* stats_bytes, int n, void* stream);
+
 /* Grouped data gradient: dst = (descs[0].accumulate ? dst : 0) + sum_i conv_i(srcs[i], wpks[i]) -- n (2..8) stride-1      */
 /* same-size convolutions (1x1 or dilated 3x3, pad = dil * (k/2)) of DIFFERENT sources with the same N, H, W, Cin, Cout   */
 /* into ONE destination.  Built for the input gradient of the ASPP bridge (pipeline:80-83: the 1x1 and the three dilated  */

@@ -817,3 +817,41 @@ def test_image_pool_branch_kernels(ops, case):
     assert float((dx[:, :Cin].float().cpu() - dxe).abs().max()) < 1e-2 * float(dxe.abs().max()) + 1e-4
     with pytest.raises(RuntimeError):
         ops.poolbranch_dx(dz, wd, cpd, dx, xp, 17, Cin, Cout)
+
+
+def test_igemm_multi_equals_the_separate_launches(ops):
+    """aau_conv_igemm_multi at the bridge shape (8 x 32 x 32, 384 -> 768: 1x1 + dilation 6 / 12 / 18 on one input, each into
+    its slice of a [.., 4 * 768]-pitch buffer with its own statistics): same bits as four aau_conv_igemm launches."""
+    N, H, W, Ci, Co = 8, 32, 32, 384, 768
+    g = torch.Generator().manual_seed(77)
+    x = dev(R.bf16_round(torch.randn(N, H, W, Ci, generator=g)).to(torch.bfloat16))
+    cp = ops.cpad_of(Ci)
+    probs = []
+    for k, dil in ((3, 6), (3, 12), (3, 18), (1, 1)):
+        w = R.bf16_round(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+        probs.append((ops.conv_desc(N, H, W, Ci, Ci, H, W, Co, Co, k, k, 1, dil * (k // 2), dil, cp), dev(pack_fwd(w, cp))))
+    descs = [p[0] for p in probs]
+    assert ops.conv_igemm_multi_ok(descs) and not ops.conv_igemm_multi_ok(descs[:1])
+    ref, refst = [], []
+    for d, wd in probs:
+        o = torch.full((N, H, W, Co), float("nan"), dtype=torch.bfloat16, device="cuda")
+        st = ops.stats_buffer(Co)
+        ops.conv_igemm(d, x, wd, o, stats=st)
+        ref.append(o)
+        refst.append(st)
+    outs = [torch.full((N, H, W, Co), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in probs]
+    sts = [ops.stats_buffer(Co) for _ in probs]
+    with launch_tags() as lt:
+        ops.conv_igemm_multi(descs, [x] * 4, [p[1] for p in probs], outs, sts)
+    assert [t.split("|")[-1] for t in lt] == ["igemm<64,192,0> multi"], lt
+    torch.cuda.synchronize()
+    for o, r_, st, rs in zip(outs, ref, sts, refst):
+        assert torch.equal(o, r_) and torch.equal(st, rs)
+    # two problems, one without statistics
+    outs2 = [torch.empty_like(outs[0]) for _ in range(2)]
+    ops.conv_igemm_multi(descs[2:], [x] * 2, [p[1] for p in probs[2:]], outs2, [None, ops.stats_buffer(Co)])
+    torch.cuda.synchronize()
+    assert torch.equal(outs2[0], ref[2]) and torch.equal(outs2[1], ref[3])
+    # a problem the wide tile does not serve is refused
+    small = ops.conv_desc(1, 16, 16, 64, 64, 16, 16, 96, 96, 1, 1, 1, 0, 1, 64)
+    assert not ops.conv_igemm_multi_ok([descs[0], small])
