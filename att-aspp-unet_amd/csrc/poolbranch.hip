@@ -6,8 +6,10 @@
 //   aau_poolbranch_fwd   z = x W^T, batch statistics, running statistics, folded scale / shift      (one launch)
 //   aau_poolbranch_bwd   BatchNorm + ReLU backward over the batch, dgamma / dbeta, dW                 (one launch)
 //   aau_poolbranch_dx    dx = dz W                                                                    (one launch)
-// A workgroup of 64 threads owns 4 output channels (forward / backward) or 4 input channels (dx); 16 lanes split the
-// reduction dimension, shuffles add the slices in a fixed order: bitwise reproducible, no atomics.
+// A workgroup of 256 threads owns 4 output channels (forward / backward) or 4 input channels (dx), one wave each; the 64 lanes
+// split the reduction dimension (8 consecutive channels per lane: one trip at 384 channels, two at 768), shuffles add the
+// slices in a fixed order: bitwise reproducible, no atomics.  (16 lanes per channel, the first form, made three dependent
+// trips of 16-byte loads per lane: 17-22 us per launch.)
 // Numerics as the generic path: 16-bit operands (packed weights, pooled activations, dz), fp32 accumulation, statistics
 // from the fp32 accumulator, z and dz stored in the 16-bit type.
 #include "common.h"
@@ -16,24 +18,24 @@ namespace aau {
 
 constexpr int PB_MAXB = 16;      // samples (training-mode BatchNorm of this branch needs >= 2)
 
-__device__ __forceinline__ float lanes16_sum(float v) {
+__device__ __forceinline__ float lanes16_sum(float v) {      // (the name is historical: all 64 lanes of the wave)
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
 // wpk: [Cout][Cpad] (the forward GEMM operand), x: [B][x_pitch]
-__global__ __launch_bounds__(64) void poolbranch_fwd_kernel(const unsigned short* x, int xp, const unsigned short* wpk, int Cpad,
+__global__ __launch_bounds__(256) void poolbranch_fwd_kernel(const unsigned short* x, int xp, const unsigned short* wpk, int Cpad,
                                                             unsigned short* z, const float* gamma, const float* beta,
                                                             float* rmean, float* rvar, long long* nbt, float* scale, float* shift,
                                                             float* smean, float* sinvstd, int B, int Cin, int Cout, float eps,
                                                             float momentum) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     float acc[PB_MAXB];
 #pragma unroll
     for (int b = 0; b < PB_MAXB; ++b) acc[b] = 0.f;
     if (c < Cout) {
-        for (int k = l * 8; k < Cin; k += 128) {                 // 8 consecutive channels per lane and trip
+        for (int k = l * 8; k < Cin; k += 512) {                 // 8 consecutive channels per lane and trip
             float w8[8];
             unpack8(*(const u32x4*)(wpk + (size_t)c * Cpad + k), w8);
 #pragma unroll
@@ -75,12 +77,12 @@ __global__ __launch_bounds__(64) void poolbranch_fwd_kernel(const unsigned short
 }
 
 // dy: [B][dyp] gradient of the ReLU output; -> dz [B][Cout] (16-bit), dgamma / dbeta +=, dw [Cout][Cin] += (fp32)
-__global__ __launch_bounds__(64) void poolbranch_bwd_kernel(const unsigned short* dy, int dyp, const unsigned short* z,
+__global__ __launch_bounds__(256) void poolbranch_bwd_kernel(const unsigned short* dy, int dyp, const unsigned short* z,
                                                             const unsigned short* x, int xp, const float* gamma,
                                                             const float* scale, const float* shift, const float* smean,
                                                             const float* sinvstd, unsigned short* dz, float* dgamma, float* dbeta,
                                                             float* dw, int B, int Cin, int Cout) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     if (c >= Cout) return;
     float g[PB_MAXB], zh[PB_MAXB], dzv[PB_MAXB];
     float s1 = 0.f, s2 = 0.f;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64) void poolbranch_bwd_kernel(const unsigned short
         dgamma[c] += s2;
         for (int b = 0; b < B; ++b) dz[(size_t)b * Cout + c] = f2bf(dzv[b]);
     }
-    for (int k = l * 8; k < Cin; k += 128) {
+    for (int k = l * 8; k < Cin; k += 512) {
         float a8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a8[j] = 0.f;
@@ -125,14 +127,14 @@ __global__ __launch_bounds__(64) void poolbranch_bwd_kernel(const unsigned short
 }
 
 // wpd: [Cin][Cpad_d] (the data-gradient operand: row k holds W[:, k]); dx [B][dxp] = dz W
-__global__ __launch_bounds__(64) void poolbranch_dx_kernel(const unsigned short* dz, const unsigned short* wpd, int Cpadd,
+__global__ __launch_bounds__(256) void poolbranch_dx_kernel(const unsigned short* dz, const unsigned short* wpd, int Cpadd,
                                                            unsigned short* dx, int dxp, int B, int Cin, int Cout) {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
     float acc[PB_MAXB];
 #pragma unroll
     for (int b = 0; b < PB_MAXB; ++b) acc[b] = 0.f;
     if (k < Cin) {
-        for (int c = l * 8; c < Cout; c += 128) {
+        for (int c = l * 8; c < Cout; c += 512) {
             float w8[8];
             unpack8(*(const u32x4*)(wpd + (size_t)k * Cpadd + c), w8);
 #pragma unroll
@@ -170,7 +172,7 @@ extern "C" int aau_poolbranch_fwd(const aau_bf16* x, int x_pitch, const aau_bf16
                 "aau_poolbranch_fwd: 16-byte rows");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(2, 2.0 * B * Cin * Cout, s);
-    hipLaunchKernelGGL(poolbranch_fwd_kernel, dim3((Cout + 3) / 4), dim3(64), 0, s, x, x_pitch, wpk, Cpad, z, gamma, beta, running_mean,
+    hipLaunchKernelGGL(poolbranch_fwd_kernel, dim3((Cout + 3) / 4), dim3(256), 0, s, x, x_pitch, wpk, Cpad, z, gamma, beta, running_mean,
                        running_var, (long long*)num_batches_tracked, scale, shift, save_mean, save_invstd, B, Cin, Cout, eps, momentum);
     return check_launch("aau_poolbranch_fwd");
 }
@@ -185,7 +187,7 @@ extern "C" int aau_poolbranch_bwd(const aau_bf16* dy, int dy_pitch, const aau_bf
     AAU_REQUIRE(x_pitch % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dw & 15) == 0, "aau_poolbranch_bwd: 16-byte rows");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(2, 2.0 * B * Cin * Cout, s);
-    hipLaunchKernelGGL(poolbranch_bwd_kernel, dim3((Cout + 3) / 4), dim3(64), 0, s, dy, dy_pitch, z, x, x_pitch, gamma, scale, shift,
+    hipLaunchKernelGGL(poolbranch_bwd_kernel, dim3((Cout + 3) / 4), dim3(256), 0, s, dy, dy_pitch, z, x, x_pitch, gamma, scale, shift,
                        save_mean, save_invstd, dz, dgamma, dbeta, dw, B, Cin, Cout);
     return check_launch("aau_poolbranch_bwd");
 }
@@ -197,6 +199,6 @@ extern "C" int aau_poolbranch_dx(const aau_bf16* dz, const aau_bf16* wpd, int Cp
     AAU_REQUIRE(Cpad_d % 8 == 0 && Cpad_d >= Cout && (((uintptr_t)dz | (uintptr_t)wpd) & 15) == 0, "aau_poolbranch_dx: 16-byte rows");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(2, 2.0 * B * Cin * Cout, s);
-    hipLaunchKernelGGL(poolbranch_dx_kernel, dim3((Cin + 3) / 4), dim3(64), 0, s, dz, wpd, Cpad_d, dx, dx_pitch, B, Cin, Cout);
+    hipLaunchKernelGGL(poolbranch_dx_kernel, dim3((Cin + 3) / 4), dim3(256), 0, s, dz, wpd, Cpad_d, dx, dx_pitch, B, Cin, Cout);
     return check_launch("aau_poolbranch_dx");
 }

@@ -710,8 +710,15 @@ class Plan:
                 alpha = self.new(Mo, dtype=F32)
                 dg = ops.conv_desc(B, ho, wo, Co, 2 * Co, ho, wo, Fi, Fi, Cpad=wg.cpad_f)
                 dx = ops.conv_desc(B, ho, wo, Co, skip_p[lv], ho, wo, Fi, Fi, Cpad=wx.cpad_f)
-                f.add("aau_conv_igemm", dg, cat[:, Co:], wg.pk_f, zg, None, None, None, wgb["stats"] if tr else None)
-                f.add("aau_conv_igemm", dx, skips[lv], wx.pk_f, zx, None, None, None, wxb["stats"] if tr else None)
+                sg_, sx_ = (wgb["stats"], wxb["stats"]) if tr else (None, None)
+                if not eng.no_igemm_multi and ops.conv_igemm_multi_ok([dg, dx]):
+                    # the gate's two 1x1 GEMMs (W_g on the up-sampled path, W_x on the skip) as one two-problem launch
+                    pack = ops.igemm_multi_args([dg, dx], [cat[:, Co:], skips[lv]], [wg.pk_f, wx.pk_f], [zg, zx], [sg_, sx_])
+                    f.keep.extend([cat, skips[lv], wg.pk_f, wx.pk_f, zg, zx, pack] + ([sg_, sx_] if tr else []))
+                    f.add("aau_conv_igemm_multi", *pack)
+                else:
+                    f.add("aau_conv_igemm", dg, cat[:, Co:], wg.pk_f, zg, None, None, None, sg_)
+                    f.add("aau_conv_igemm", dx, skips[lv], wx.pk_f, zx, None, None, None, sx_)
                 if tr:
                     self._bn_finalize(bg, wgb, Mo)
                     self._bn_finalize(bx, wxb, Mo)
