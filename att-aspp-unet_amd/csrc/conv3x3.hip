@@ -1849,18 +1849,12 @@ __global__ __launch_bounds__(512) void conv3x3_resw2_kernel(const C3Args a, int 
 // multiplied.  Round 2 shipped NBUF = 2, i.e. ONE 16-KB tile of look-ahead per CU: at ~1.1 us from issue to landing that
 // caps a CU at ~15 GB/s (3.7 TB/s chip-wide; measured 2.2-3.4 TB/s on these byte-bound layers).  The weights of these
 // layers are small (<= 48 KB), so the ring can hold 7 tiles = 96 KB in flight per CU.
-// STAGED: the epilogue goes through LDS.  In the MFMA layout a lane owns 8 channels of one pixel: a wave-wide store is 64
-// pieces of 16 B in 64 different 96- / 192-byte rows (and for the ConvTranspose pixel shuffle in 64 different output
-// pixels, two pixels apart) -- timing ablations put 45 % of the transposed-conv time there.  Staged, the 256 x BQ tile is
-// written to LDS as 16-bit values and copied out so that a wave-wide store (or read-modify-write) covers one contiguous
-// KiB of the destination: whole 16-pixel rows, for the pixel shuffle whole 32-pixel output rows.
-template <int BQ, int NW, int NBUF, bool STAGED, int ABL = 0>
+// (An LDS-staged, fully coalesced epilogue -- whole 16-pixel / 32-output-pixel rows per wave-wide store -- measured 0-15 %
+// SLOWER than the per-lane 16-byte stores on every layer and was removed: profiles/NOTES.md.)
+template <int BQ, int NW, int NBUF, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, int npatch) {
     constexpr int BK = 32, HW_ = 16, HROWS = HW_ * HW_, HPAD = 256, NI = BQ / 16, MI = 16 / NW;
-    // STAGED: the first half of the waves issues every fill, the second half every output store (and the read of an
-    // accumulating destination).  vmcnt retires in issue order, so a wave that mixes both waits for its stores' write
-    // acknowledgements (and for a read-modify-write's loads, behind ALL its fills) before it may touch a landed tile.
-    constexpr int NWF = STAGED ? NW / 2 : NW;          // waves that fill
+    constexpr int NWF = NW;                            // waves that fill
     constexpr int HL = 16 / NWF;
     constexpr int HALO_E = HPAD * BK, WT_E = BQ * BK;
     constexpr unsigned OOB = 0x80000000u;
@@ -1986,9 +1980,7 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             // tile t must have landed: the younger operations are the fills of tiles t+1 .. t+PD-1 (HL instructions per
             // wave each) and output stores issued between them; waiting down to the fills alone is exact when no store
             // is younger than tile t and at worst also retires a few fills that were issued PD-2 steps ago
-            if constexpr (PD == 1 && STAGED) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else if constexpr (PD == 1) {
+            if constexpr (PD == 1) {
                 if (t > 0 && chunk == 0 && full_tiles && wide) {          // half as many (16-byte) stores per lane
                     if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     else if constexpr (NI * MI == 12) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -2040,85 +2032,6 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
         // ---- per-patch epilogue ----
         int n, y0, x0;
         patch_origin(patch, n, y0, x0);
-        if constexpr (STAGED) {
-            constexpr int PXS = BQ * 2 + 16;                         // LDS bytes per staged pixel (+16: bank spread)
-            unsigned char* sO = (unsigned char*)par + 3 * BQ * 4;   // [256 px][PXS]
-            // 1. every lane: its accumulators (+ bias / affine, statistics) as 16-bit values, 8 channels of one pixel per piece
-#pragma unroll
-            for (int mp = 0; mp < MI; mp += 2) {
-                const int rl = wave * MI + mp + (fk & 1);            // patch row this lane owns after the swap
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int q = q0 + ni * 16 + 4 * fk;
-                    float va[4], vb[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { va[r] = acc[ni][mp][r]; vb[r] = acc[ni][mp + 1][r]; }
-                    if (q < d.Cout) {
-                        if (want_stats) { epi_stats(a, 0, q, va, s1[ni], s2[ni]); epi_stats(a, 0, q, vb, s1[ni], s2[ni]); }
-                        const int ql = ni * 16 + 4 * fk;
-                        if (a.bias) {
-                            const f32x4 b = *(const f32x4*)(par + ql);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
-                        }
-                        if (a.scale) {
-                            const f32x4 sc = *(const f32x4*)(par + BQ + ql);
-                            const f32x4 sh = *(const f32x4*)(par + 2 * BQ + ql);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
-                        }
-                    }
-                    float w[8];
-                    swap_pair8(va, vb, w);
-                    *(u32x4*)(sO + (rl * 16 + fr) * PXS + (ni * 16 + 8 * (fk >> 1)) * 2) = pack8(w);
-                }
-            }
-            __syncthreads();
-            // 2. copy out: piece p = (pixel, 8-channel part) in DESTINATION order
-            constexpr int PARTS = BQ / 8;
-            const int Co = d.Cout >> 2;
-            for (int p = tid - 64 * NWF; p >= 0 && p < 256 * PARTS; p += 64 * (NW - NWF)) {
-                int px, part;
-                unsigned short* out;
-                if (d.shuffle2x2) {
-                    // order [patch row][output row of the pair, when the tile holds both][input pixel x][its parts]: a
-                    // wave-wide store runs along ONE output row (channel tiles never straddle an output row: host check)
-                    const int norow = BQ >= 4 * Co ? 2 : 1, ppr = PARTS / norow;
-                    const int yy = p / (norow * 16 * ppr), rem = p - yy * (norow * 16 * ppr);
-                    const int orow = rem / (16 * ppr), rem2 = rem - orow * (16 * ppr);
-                    const int xx = rem2 / ppr, pp = rem2 - xx * ppr;
-                    px = yy * 16 + xx; part = orow * ppr + pp;
-                    const int qw = q0 + part * 8;
-                    if (qw >= d.Cout) continue;
-                    const int pos = qw / Co;
-                    const int64_t op = ((int64_t)n * (2 * d.H) + (2 * (y0 + yy) + (pos >> 1))) * (2 * d.W) + (2 * (x0 + xx) + (pos & 1));
-                    out = a.dst + op * d.dst_pitch + (qw - pos * Co);
-                } else {
-                    px = p / PARTS; part = p - px * PARTS;
-                    const int qw = q0 + part * 8;
-                    if (qw >= d.Cout) continue;
-                    out = a.dst + (((int64_t)n * d.H + y0 + (px >> 4)) * d.W + x0 + (px & 15)) * d.dst_pitch + qw;
-                }
-                u32x4 v = *(const u32x4*)(sO + px * PXS + part * 16);
-                if (d.accumulate || d.relu) {
-                    float w[8];
-                    unpack8(v, w);
-                    if (d.accumulate) {
-                        float o[8];
-                        unpack8(*(const u32x4*)out, o);
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) w[r] += o[r];
-                    }
-                    if (d.relu) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
-                    }
-                    v = pack8(w);
-                }
-                *(u32x4*)out = v;
-            }
-            continue;
-        }
         if (wide) {
             static_assert(MI % 2 == 0, "pixel rows are stored in pairs");
             const int Co = d.Cout >> 2;
@@ -2292,22 +2205,11 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     const int ntq = (d->Cout + BQ - 1) / BQ;
     const int npatch = a.tiles_x * a.tiles_y * d->N;
     const size_t wbytes = ((size_t)a.nchunk * BQ * 64 + 8191) / 8192 * 8192;   // whole staging rounds of 512 threads
-    // LDS: ring of pixel tiles (16 KB each) | weights | per-channel vectors | (staged form) the 256 x BQ output tile.
-    // Staged epilogue (coalesced stores) needs 16-byte-aligned rows; the pixel shuffle needs the whole 4 Co channels in one
-    // tiles must not straddle an output row of the 2x2 pair (BQ = 4 Co, or BQ dividing 2 Co).
-    const size_t stage = (size_t)256 * (BQ * 2 + 16);
-    const bool aligned = ((uintptr_t)dst & 15) == 0 && d->dst_pitch % 8 == 0 && d->Cout % 8 == 0;
-    const int Co4 = d->Cout >> 2;
-    bool staged = aligned && (!d->shuffle2x2 || (Co4 % 8 == 0 && (BQ == 4 * Co4 || (2 * Co4) % BQ == 0))) &&
-                  getenv("AAU_PW_STAGE") && !getenv("AAU_NO_WIDE_STORE");
-    // (measured, round 3: the LDS-staged coalesced epilogue is 0-15 % SLOWER than the per-lane 16-byte stores on every
-    // layer that takes this kernel, with or without the fill / store role split -- the stores are not what bounds it;
-    // the deeper ring alone gives 5-8 %.  Staged form = experiment switch AAU_PW_STAGE=1.)
-    int nbuf = staged ? 4 : 7;
-    if ((size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + (staged ? stage : 0) > 160 * 1024) { nbuf = 2; }
-    if ((size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + (staged ? stage : 0) > 160 * 1024) { staged = false; }
-    if (const char* e = getenv("AAU_PW_NBUF")) { if (atoi(e) == 2) { nbuf = 2; staged = false; } }   // experiment: round-2 form
-    const size_t lds = (size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + (staged ? stage : 0);
+    // LDS: ring of pixel tiles (16 KB each) | weights | per-channel vectors
+    int nbuf = 7;
+    if ((size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 > 160 * 1024) { nbuf = 2; }
+    if (const char* e = getenv("AAU_PW_NBUF")) { if (atoi(e) == 2) nbuf = 2; }   // A/B: round 2's one tile of look-ahead
+    const size_t lds = (size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4;
     int per_cu = lds <= 80 * 1024 ? 2 : 1;
     if (const char* e = getenv("AAU_PW_PERCU")) per_cu = atoi(e);   // experiment
     int gx = 256 * per_cu / ntq;
@@ -2320,26 +2222,22 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
         hipLaunchKernelGGL(kern, dim3(gx, ntq), dim3(512), lds, s, a, npatch);
     };
     if (BQ == 48) {
-        if (staged && nbuf == 4) go(conv1x1_resw_kernel<48, 8, 4, true>);
-        else if (staged) go(conv1x1_resw_kernel<48, 8, 2, true>);
-        else if (nbuf == 7) go(conv1x1_resw_kernel<48, 8, 7, false>);
-        else go(conv1x1_resw_kernel<48, 8, 2, false>);
+        if (nbuf == 7) go(conv1x1_resw_kernel<48, 8, 7>);
+        else go(conv1x1_resw_kernel<48, 8, 2>);
     } else {
-        if (staged && nbuf == 4) go(conv1x1_resw_kernel<96, 8, 4, true>);
-        else if (staged) go(conv1x1_resw_kernel<96, 8, 2, true>);
-        else if (nbuf == 7) go(conv1x1_resw_kernel<96, 8, 7, false>);
-        else go(conv1x1_resw_kernel<96, 8, 2, false>);
+        if (nbuf == 7) go(conv1x1_resw_kernel<96, 8, 7>);
+        else go(conv1x1_resw_kernel<96, 8, 2>);
     }
 #ifdef AAU_C3S_ABLATE
     // (the launch above already ran; an ablation run times BOTH and the difference is what the switch removes)
     if (const char* e = getenv("AAU_PW_ABL")) {
         const int abl = atoi(e);
-        if (BQ == 96 && abl == 2) go(conv1x1_resw_kernel<96, 8, 7, false, 2>);
-        if (BQ == 96 && abl == 4) go(conv1x1_resw_kernel<96, 8, 7, false, 4>);
-        if (BQ == 96 && abl == 6) go(conv1x1_resw_kernel<96, 8, 7, false, 6>);
-        if (BQ == 48 && abl == 2) go(conv1x1_resw_kernel<48, 8, 7, false, 2>);
-        if (BQ == 48 && abl == 4) go(conv1x1_resw_kernel<48, 8, 7, false, 4>);
-        if (BQ == 48 && abl == 6) go(conv1x1_resw_kernel<48, 8, 7, false, 6>);
+        if (BQ == 96 && abl == 2) go(conv1x1_resw_kernel<96, 8, 7, 2>);
+        if (BQ == 96 && abl == 4) go(conv1x1_resw_kernel<96, 8, 7, 4>);
+        if (BQ == 96 && abl == 6) go(conv1x1_resw_kernel<96, 8, 7, 6>);
+        if (BQ == 48 && abl == 2) go(conv1x1_resw_kernel<48, 8, 7, 2>);
+        if (BQ == 48 && abl == 4) go(conv1x1_resw_kernel<48, 8, 7, 4>);
+        if (BQ == 48 && abl == 6) go(conv1x1_resw_kernel<48, 8, 7, 6>);
     }
 #endif
     return check_launch("aau_conv_igemm(1x1 resident weights)");

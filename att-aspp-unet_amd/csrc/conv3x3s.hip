@@ -18,9 +18,6 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
-#ifndef AAU_FILL_AUX
-#define AAU_FILL_AUX 0      // cache policy of the activation fills (2 = nt: measured)
-#endif
 #include "c3args.h"
 
 namespace aau {
@@ -89,10 +86,10 @@ __device__ __forceinline__ void epi_pair_store(const C3Args& a, const aau_conv_d
 // A work unit is a vertical segment of one 16-pixel-wide strip of one image: `segh` patches (the last segment of a strip
 // may be shorter).  The fill stream of a unit is blocks b = -1 .. K-1 of 16 image rows: block b holds rows
 // ys + 16 b + 1 .. ys + 16 b + 16, patch b (rows ys + 16 b ...) needs the last two rows of block b-1 and all of block b.
-// NWV waves per workgroup and PR patch rows: (12, 16) = one workgroup per CU, (6, 8) = TWO independent workgroups per CU
-// (half the ring each): while one of them sits in its barrier / epilogue / first-fragment latency the other one keeps the
-// matrix pipes busy -- with one workgroup per CU all twelve waves go through those phases together.
-template <int CIN, int G, int NWV, int PR, int ABL, bool STAG, bool BNRED>
+// NWV = 12 waves per workgroup (one workgroup per CU), PR = 16 patch rows.  (Two independent 6-wave workgroups per CU on
+// 8-row patches measured 20-30 % slower -- twice the barriers, 10 halo rows per 8 -- and an epilogue staggered between the
+// two halves of the waves 0-10 % slower: profiles/NOTES.md.)
+template <int CIN, int G, int NWV, int PR, int ABL, bool BNRED>
 __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, int nunits, int strips, int nseg, int segh) {
     constexpr int abl = ABL;                           // timing ablations (AAU_C3S_ABL; builds with -DAAU_C3S_ABLATE only)
     constexpr int PXB = CIN == 48 ? 96 : 224;          // bytes per pixel in LDS
@@ -101,7 +98,8 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
     constexpr int ROWB = CIN == 48 ? 2048 : 4096;      // bytes per ring row (18 px, padded to whole 1-KiB DMA pieces)
     constexpr int IPR = ROWB / 1024;                   // LDS-DMA instructions per row
     constexpr int D = CIN == 48 ? 2 : 1;               // blocks in flight
-    constexpr int R = PR == 16 ? (CIN == 48 ? 64 : 36) : (CIN == 48 ? 26 : 18);   // ring rows
+    static_assert(PR == 16, "ring sizes below");
+    constexpr int R = CIN == 48 ? 64 : 36;             // ring rows
     constexpr int FW = NWV / IPR * IPR;                // waves that issue fills (a lane's piece of a row must not depend on i)
     constexpr int NF = (PR * IPR + FW - 1) / FW;       // fill instructions per wave and block
     constexpr int SLOTS = NWV / G;                     // row-quad slots
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
         unsigned char* dstp = real ? dsm + rr * ROWB + sub * 1024 : dsm + R * ROWB;
         const unsigned soff = row_ok ? (unsigned)(((in_ * d.H + y) * d.W) * d.src_pitch * 2) : 0u;
         const unsigned v = (row_ok && !(abl & 2)) ? ivec : OOB;       // abl: timing ablations (AAU_C3S_ABL), never set in production
-        if (!(abl & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, AAU_FILL_AUX);
+        if (!(abl & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, 0);
     };
     auto issue_end = [&]() {
         irb += PR; if (irb >= R) irb -= R;
@@ -231,13 +229,6 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
 
     int crb = 0;                               // ring row of block t
     bool prev_patch = false;
-    // STAGGER: the second half of the waves runs the epilogue of its LAST row quad of a patch behind the NEXT barrier, so
-    // that it overlaps with the first half's MFMAs (and the first half's epilogues with the second half's MFMAs) instead
-    // of all twelve waves doing their vector / store work at the same time with the matrix pipes idle.  The accumulators
-    // simply stay alive across the barrier.  (SIMD partners are waves w, w + 4, w + 8: every SIMD gets both kinds.)
-    const bool late = STAG && wave >= NWV / 2;
-    bool pend = false;
-    unsigned pend_soff = 0;
     f32x4 acc[4];
     // BNRED: the consuming layer's raw conv outputs at this lane's (pixel, 4 channels) of the four rows of the quad, loaded
     // BEFORE the quad's MFMA stream (their latency hides behind it; they are older than the fills issued during the
@@ -273,13 +264,10 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
             // block t has landed: the only younger operations are the fills of the blocks behind it and the previous
             // patch's stores (vmcnt retires in issue order)
             if (!(abl & 16)) {
-                // (a late wave's deferred stores were issued BEFORE the fills it waits for here)
                 if (!prev_patch) wait_vm_s<NF * (D - 1)>();
-                else if (late) wait_vm_s<NF * (D - 1) + NST - 2>();
                 else wait_vm_s<NF * (D - 1) + NST>();
                 __builtin_amdgcn_s_barrier();
             }
-            if (pend) { epilogue(pend_soff); pend = false; }
             // block t + D goes into rows nobody reads any more; on a patch step its NF instructions are issued between
             // the K-blocks of the first row quad instead of in one burst behind the barrier
             prev_patch = cb >= 0;
@@ -329,14 +317,12 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
                         continue;
                     }
                     const unsigned soff = (unsigned)((((n * d.H + y0 + 4 * q) * d.W) + x0) * d.dst_pitch * 2);
-                    if (late && qi == NQ - 1) { pend = true; pend_soff = soff; }
-                    else epilogue(soff);
+                    epilogue(soff);
                 }
             }
             crb += PR; if (crb >= R) crb -= R;
         }
     }
-    if (pend) epilogue(pend_soff);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (want_stats) {
         // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
@@ -375,14 +361,7 @@ bool conv3x3s_applicable(const aau_conv_desc* d, const void* src, const void* ds
 int conv3x3s_launch(C3Args& a, hipStream_t s) {
     const aau_conv_desc& d = a.d;
     const bool c48 = d.Cin == 48, g3 = d.Cout == 48;
-    // two 6-wave workgroups per CU on 8-row patches (see the kernel), one 12-wave workgroup on 16-row patches otherwise
-    // (measured: two 6-wave workgroups per CU on 8-row patches are 20-30 % SLOWER -- twice the barriers, 10 halo rows per
-    // 8 -- so one 12-wave workgroup is the default and mode 2 an experiment switch)
-    int mode = 1;
-    if (const char* e = getenv("AAU_C3S_MODE")) mode = atoi(e);
-    if (a.bn_z) mode = 1;
-    const bool stag = getenv("AAU_C3S_STAG") != nullptr;      // staggered epilogues: measured 0-10 % slower, experiment only
-    const int PR = mode == 2 ? 8 : 16, per_cu = mode == 2 ? 2 : 1;
+    constexpr int PR = 16, per_cu = 1;          // one 12-wave workgroup per CU on 16-row patches
     const int strips = d.W / 16, tiles_y = d.H / PR;
     // cut the strips into vertical segments until every workgroup slot has a unit (each segment restarts the row stream:
     // at least two patches per segment where the image allows it)
@@ -393,7 +372,7 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
     const int64_t nunits = (int64_t)d.N * strips * nseg;
     if (nunits > 0x7fffffff) { set_error("conv3x3s: too many units"); return AAU_E_INVALID; }
     const int grid = nunits < 256 * per_cu ? (int)nunits : 256 * per_cu;
-    const size_t ring = mode == 2 ? (c48 ? (size_t)26 * 2048 : (size_t)18 * 4096) : (c48 ? (size_t)64 * 2048 : (size_t)36 * 4096);
+    const size_t ring = c48 ? (size_t)64 * 2048 : (size_t)36 * 4096;
     const size_t lds = ring + 1024 + 4 * 96 * 4;
     int abl = 0;
     if (const char* e = getenv("AAU_C3S_ABL")) abl = atoi(e);       // timing ablations: 1 no MFMA, 2 fills out of range, 4 no stores, 8 no epilogue, 16 no barrier / wait, 32 no fill instructions
@@ -404,29 +383,15 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, a, (int)nunits, strips, nseg, segh);
     };
     if (a.bn_z) {          // fused BatchNorm-backward sums (aau_conv_igemm_bnred): the default form only, 48 input channels
-        go(conv3x3s_kernel<48, 3, 12, 16, 0, false, true>, 768);      // 48 -> 48 (the 48 -> 96 form spills at 168 VGPRs)
+        go(conv3x3s_kernel<48, 3, 12, 16, 0, true>, 768);      // 48 -> 48 (the 48 -> 96 form spills at 168 VGPRs)
         return check_launch("aau_conv_igemm_bnred(3x3 strips)");
     }
     auto pick = [&](auto ablc) {
         constexpr int A = decltype(ablc)::value;
-        if (mode == 2) {
-            if (c48 && g3) go(conv3x3s_kernel<48, 3, 6, 8, A, false, false>, 384);
-            else if (c48) go(conv3x3s_kernel<48, 6, 6, 8, A, false, false>, 384);
-            else if (g3) go(conv3x3s_kernel<96, 3, 6, 8, A, false, false>, 384);
-            else go(conv3x3s_kernel<96, 6, 6, 8, A, false, false>, 384);
-        } else {
-            if (stag) {
-                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, true, false>, 768);
-                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, true, false>, 768);
-                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, true, false>, 768);
-                else go(conv3x3s_kernel<96, 6, 12, 16, A, true, false>, 768);
-            } else {
-                if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, false, false>, 768);
-                else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, false, false>, 768);
-                else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, false, false>, 768);
-                else go(conv3x3s_kernel<96, 6, 12, 16, A, false, false>, 768);
-            }
-        }
+        if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, A, false>, 768);
+        else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, A, false>, 768);
+        else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, A, false>, 768);
+        else go(conv3x3s_kernel<96, 6, 12, 16, A, false>, 768);
     };
     switch (abl) {
 #ifdef AAU_C3S_ABLATE

@@ -718,6 +718,7 @@ __global__ void fold_stats_kernel(const long long* stats, int C, int which, int 
 }
 // out[i] += total of statistic 0 of channel cA + i of buffer A (+ of channel cB + i of buffer B): 32 lanes per channel, one
 // replica each, exact integer limb sums through shuffles (the same value as stat_total, a quarter of its dependent loads)
+static_assert(AAU_STAT_REPLICAS == 32, "fold_stats_pair_kernel: one lane of a 32-lane group per replica (threadIdx & 31, shuffle offsets 16..1)");
 __global__ __launch_bounds__(256) void fold_stats_pair_kernel(const long long* A, int CA, int cA, const long long* Bs, int CB, int cB,
                                                                int n, float* out) {
     const int i = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;

@@ -158,9 +158,12 @@ __global__ __launch_bounds__(256) void poolbranch_dx_kernel(const unsigned short
 
 using namespace aau;
 
+// B >= 2: BatchNorm over the B pooled vectors in training mode -- with one sample per channel the variance is 0 and the
+// reference's BatchNorm2d raises "Expected more than 1 value per channel when training" (pipeline:75-77)
 #define PB_CHECK(fn, B, Cin, Cout)                                                                                         \
-    AAU_REQUIRE((B) >= 1 && (B) <= PB_MAXB && (Cin) >= 8 && (Cin) % 8 == 0 && (Cout) >= 8 && (Cout) % 8 == 0,                 \
-                fn ": B=%d (1..%d), Cin=%d, Cout=%d (multiples of 8)", (int)(B), PB_MAXB, (int)(Cin), (int)(Cout))
+    AAU_REQUIRE((B) >= 2 && (B) <= PB_MAXB && (Cin) >= 8 && (Cin) % 8 == 0 && (Cout) >= 8 && (Cout) % 8 == 0,                 \
+                fn ": B=%d (2..%d: training-mode BatchNorm needs more than 1 value per channel), Cin=%d, Cout=%d (multiples of 8)", \
+                (int)(B), PB_MAXB, (int)(Cin), (int)(Cout))
 
 extern "C" int aau_poolbranch_fwd(const aau_bf16* x, int x_pitch, const aau_bf16* wpk, int Cpad, aau_bf16* z, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,

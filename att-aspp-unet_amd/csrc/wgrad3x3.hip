@@ -20,9 +20,6 @@
 // ranges, fp32 atomics into the channels_last gradient [Cout][9][Cin].
 #include <stdlib.h>
 #include "common.h"
-#ifndef AAU_FILL_AUX
-#define AAU_FILL_AUX 0      // cache policy of the activation fills (2 = nt: measured)
-#endif
 
 namespace aau {
 
@@ -141,14 +138,14 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
 #pragma unroll
         for (int i = 0; i < NLY; ++i) {
             const unsigned v = yrel[i] >= 0 ? (unsigned)((org * d.dst_pitch + yrel[i]) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY(buf) + (i * NW + wave) * 1024), 16, (int)v, 0, 0, AAU_FILL_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY(buf) + (i * NW + wave) * 1024), 16, (int)v, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
             const int y = y0 - 1 + xhy[i], x = x0 - 1 + xhx[i];
             const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
             const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + xch[i]) * 2) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX(buf) + (i * NW + wave) * 1024), 16, (int)v, 0, 0, AAU_FILL_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX(buf) + (i * NW + wave) * 1024), 16, (int)v, 0, 0, 0);
         }
     };
 

@@ -173,17 +173,28 @@ class _Rec:
 
 
 class _Arena:
+    """Bump allocator over device buffers that are cleared together once per pass (``zero_``).  The first buffer is sized
+    by the caller's estimate; a ``take`` that does not fit opens another one (the takes themselves size the arena: a new
+    fused path that needs a few more words cannot overrun a constant)."""
+
     def __init__(self, n, device, dtype=F32):
-        self.buf = torch.zeros(max(int(n), 16), dtype=dtype, device=device)
+        self.device, self.dtype = device, dtype
+        self.grow = max(int(n), 16)
+        self.bufs = [torch.zeros(self.grow, dtype=dtype, device=device)]
         self.off = 0
 
     def take(self, n):
         n4 = _ru(int(n), 4)
-        if self.off + n4 > self.buf.numel():
-            raise RuntimeError("arena exhausted")
-        t = self.buf[self.off:self.off + n]
+        if self.off + n4 > self.bufs[-1].numel():
+            self.bufs.append(torch.zeros(max(self.grow, n4), dtype=self.dtype, device=self.device))
+            self.off = 0
+        t = self.bufs[-1][self.off:self.off + n]
         self.off += n4
         return t
+
+    def zero_(self):
+        for b in self.bufs:
+            b.zero_()
 
 
 class ConvP:
@@ -330,9 +341,12 @@ class Plan:
     """Recorded forward (and backward) launch lists for one input shape / mode."""
 
     def __init__(self, eng: "Engine", B: int, H: int, W: int, train: bool):
-        assert H % 16 == 0 and W % 16 == 0, "H and W must be multiples of 16 (four 2x2 poolings)"
-        if train:
-            assert B >= 2, "training-mode BatchNorm of the ASPP image-pool branch needs batch >= 2 (pipeline:75-77)"
+        if B < 1 or H < 16 or W < 16 or H % 16 or W % 16:
+            raise _abi.AauError(f"input {B}x1x{H}x{W}: H and W must be positive multiples of 16 (four 2x2 poolings; the "
+                                "reference's bilinear fix-up of odd sizes, pipeline:106-107, is not built)")
+        if train and B < 2:
+            raise _abi.AauError("training-mode BatchNorm of the ASPP image-pool branch needs batch >= 2 (pipeline:75-77: "
+                                "'Expected more than 1 value per channel when training')")
         self.eng, self.B, self.H, self.W, self.train = eng, B, H, W, train
         self.dev = eng.store.device
         self.fwd, self.bwd = _Rec(), _Rec()
@@ -957,7 +971,7 @@ class Plan:
             self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
         if self.train:
             self.fwd_gen += 1
-            self.stats_arena.buf.zero_()
+            self.stats_arena.zero_()
             self.drop_seed.add_(0x9E3779B97F4A7C15 - (1 << 64))   # odd increment mod 2^64: a new mask every step
         self.fwd.run(stream)
         return self.logits
@@ -966,8 +980,8 @@ class Plan:
         st = self.eng.store
         if dlogits is not None and dlogits.data_ptr() != self.dlogits.data_ptr():
             self.dlogits.copy_(dlogits.reshape(self.dlogits.shape), non_blocking=True)
-        self.red_arena.buf.zero_()
-        self.bstats_arena.buf.zero_()
+        self.red_arena.zero_()
+        self.bstats_arena.zero_()
         st.gflat.zero_()
 
     def run_backward(self, dlogits: torch.Tensor | None):
@@ -987,6 +1001,7 @@ class Engine:
         self.precision = "bf16"  # 16-bit storage type of the launch lists: "bf16", or "fp16" (inference only)
         self._seed = None       # dropout seed chain: drawn from torch's RNG (and the DP rank) on first use
         self.bucket_cb = None   # set by the data-parallel wrapper: name -> callable
+        self.dp = None          # the data-parallel wrapper itself (gradient accumulation is finished by it: model._NetFn)
         import os
         self.overlap_wgrad = os.environ.get("AAU_OVERLAP_WGRAD", "0") == "1"   # measured null on MI355X (A/B, same device)
         self.no_fuse_conv1 = os.environ.get("AAU_NO_FUSE_CONV1", "0") == "1"   # experiment switches

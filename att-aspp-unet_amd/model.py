@@ -142,8 +142,14 @@ class _NetFn(torch.autograd.Function):
         plan.bwd_gen = ctx.gen
         st = plan.eng.store
         keep = st.gflat.clone() if any(p.grad is not None for p in st.params) else None
+        dp = plan.eng.dp
+        if dp is not None:
+            # data parallel: the bucket all-reduces run asynchronously IN PLACE on the flat buffer while the backward
+            # goes on, so the kept (already reduced) gradient must not touch it before they are done --
+            # DataParallel.finish() adds it behind the last of them
+            dp.before_backward(keep)
         plan.run_backward(dlogits.contiguous())
-        if keep is not None:
+        if keep is not None and dp is None:
             st.gflat.add_(keep)
         return None, None, None
 

@@ -89,7 +89,9 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.inv_scale = 1.0 / self.world
         self.reducer = None
+        self.pending = None     # gradient kept over an accumulating backward, added back by finish()
         model.engine.bucket_cb = self._on_mark
+        model.engine.dp = self
         # identical starting weights on every rank
         st = model.engine.store
         tensors = [st.flat] if st is not None else [p.data for p in model.parameters()]
@@ -106,8 +108,24 @@ class DataParallel:
     def _on_mark(self, mark):
         self._ensure().on_mark(mark)
 
+    def before_backward(self, keep):
+        """Called by the autograd node before a backward.  ``keep``: the flat gradient of earlier forward / backward pairs
+        (``.grad`` not cleared: torch's accumulation semantics) or None.  The backward rewrites the flat buffer and the
+        bucket all-reduces work on it in place and asynchronously, so ``keep`` -- which is ALREADY reduced -- is only
+        added once they are done, in ``finish()``; adding it on the compute stream right after the backward could
+        run before or during a bucket's all-reduce and be summed world-size times or torn."""
+        red = self._ensure()
+        if red.works or self.pending is not None:
+            raise RuntimeError("DataParallel.finish() must be called after every backward (the previous backward's "
+                               "bucket all-reduces are still outstanding)")
+        self.pending = keep
+
     def finish(self):
-        self._ensure().finish()
+        red = self._ensure()
+        red.finish()
+        if self.pending is not None:
+            red.flat.add_(self.pending)
+            self.pending = None
 
     def sync_buffers(self, src: int = 0):
         """Broadcast rank ``src``'s module buffers (BatchNorm running mean / var / count): they are updated from each

@@ -7,7 +7,7 @@ batch 8 per GPU, bf16 activations / fp32 master weights, synthetic ultrasound ph
 
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   roofline     the DOMINANT KERNEL of the step (the kernel variant with the largest summed time among
-               the MFMA convolution launches; today conv3x3g<96>): algorithmic FLOPs of its launches /
+               the MFMA convolution launches; today conv3x3p<96>): algorithmic FLOPs of its launches /
                their summed duration, measured live with HIP events around every launch on the launch
                stream in a second (eager) pass of the same steps.  Beside it: `conv_family` (all conv
                launches against the 680.05 GFLOP/image of BASELINE.md section 2), `by_kernel` (every conv
@@ -269,6 +269,75 @@ def launch_selftest(world, rank):
     dist.destroy_process_group()
 
 
+def ranks_seen(world, dev):
+    """Every rank adds 1 over the process group (RCCL at N > 1): the sum is the number of ranks the collective library
+    really connected, which `n_gpus` (WORLD_SIZE echoed back) does not prove.  1 without a process group."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    return int(round(float(t.item())))
+
+
+def dp_overlap_numbers(dp, step, x, y, reps=5):
+    """Data-parallel overlap evidence (every rank runs this; collectives inside): per gradient bucket the bytes, the
+    all-reduce time ALONE (blocking, nothing else on the device, median of `reps`) and the time of the backward kernels
+    that run BEHIND its mark in a real step (HIP events on the compute stream at the mark and at the end of the
+    backward) -- a bucket is hidden when the second exceeds the first; plus the step without any all-reduce."""
+    import torch.distributed as dist
+    red = dp._ensure()
+    ev = {}
+    orig = red.on_mark
+
+    def on_mark(mark):
+        if mark in red.ranges:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev[mark] = e
+        orig(mark)
+    red.on_mark = on_mark
+    fin = dp.finish
+    end = torch.cuda.Event(enable_timing=True)
+
+    def finish():
+        end.record()                      # the backward list has been enqueued; the waits for the buckets follow
+        fin()
+    dp.finish = finish
+    step(x, y)
+    torch.cuda.synchronize()
+    red.on_mark, dp.finish = orig, fin
+    behind = {m: e.elapsed_time(end) for m, e in ev.items()}
+    out = {}
+    for mark, (b, e) in red.ranges.items():
+        buf = torch.zeros(e - b, device=x.device)
+        ts = []
+        for _ in range(reps):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        out[mark] = {"mbytes": (e - b) * 4 / 1e6, "allreduce_ms_alone": ts[len(ts) // 2],
+                     "backward_ms_behind_its_mark": behind.get(mark)}
+    # the same steps with the all-reduces left out (every rank trains on its own gradient: timing only)
+    red.on_mark = lambda mark: red.fired.append(mark) if mark in red.ranges else None
+    for _ in range(2):
+        step(x, y)
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step(x, y)
+    torch.cuda.synchronize()
+    alone = (time.perf_counter() - t0) / reps * 1e3
+    red.on_mark = orig
+    dist.barrier()
+    return {"buckets": out, "eager_step_ms_without_allreduce": alone}
+
+
 def loader_numbers(dev, n=96):
     """Feed rate of the input pipeline (not the metric): n synthetic 562x744 PNG frames + masks on
     local disk -> DirectoryLoader (thread-pool decode, GPU Resize + the random augmentations of pipeline:149-153) -> batches
@@ -369,6 +438,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    seen = ranks_seen(world, dev)            # before the timed loop: what the collective library connected
+
     run = step
     graphed = False
     for i in range(a.warmup):
@@ -447,6 +518,15 @@ def main():
             x.copy_(xh, non_blocking=True); y.copy_(yh, non_blocking=True); run(x, y)
         torch.cuda.synchronize()
         h2d = a.batch * nh / (time.perf_counter() - t1)
+    overlap = None
+    if dp is not None and not a.no_roofline:
+        overlap = dp_overlap_numbers(dp, step, x, y)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step(x, y)
+        torch.cuda.synchronize()
+        overlap["eager_step_ms_with_allreduce"] = (time.perf_counter() - t1) / 3 * 1e3
+        overlap["exposed_allreduce_ms"] = overlap["eager_step_ms_with_allreduce"] - overlap["eager_step_ms_without_allreduce"]
     if world > 1:
         dist.barrier()
 
@@ -477,6 +557,8 @@ def main():
                                    f"base_c {a.base_c}, 1x{a.size}x{a.size}, batch {a.batch}/GPU, bf16 activations, "
                                    f"fp32 master weights" + (", RCCL grad all-reduce overlapped with backward" if world > 1 else ""),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "hipgraph": graphed,
+                       "rccl_ranks_seen": seen, "collective_backend": (backend if dist.is_initialized() else None),
+                       "images_per_sec_per_gpu": imgs / dt / world, "overlap": overlap,
                        "final_loss": loss_val, "images_per_sec_with_h2d_of_inputs": h2d,
                        "inference_not_the_metric": infer, "input_pipeline_not_the_metric": loader},
             "roofline": roof, "cpu_baseline": cpu,

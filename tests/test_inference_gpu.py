@@ -105,9 +105,10 @@ def test_one_model_many_shapes_and_modes(A, trained):
     assert torch.equal(a8, again)                         # eval forward is deterministic (no atomics on this path)
     assert torch.allclose(a8[:3], a3, atol=1e-5)
     assert a1.shape == (1, 1, 64, 96) and bool(torch.isfinite(a1).all())
-    with pytest.raises(Exception):
-        m(x[:, :, :60, :60])               # H, W must be multiples of 16
+    from att_aspp_unet_amd._abi import AauError
+    with pytest.raises(AauError):
+        m(x[:, :, :60, :60])               # H, W must be multiples of 16: the documented error, not a bare assert
     m.train()
-    with pytest.raises(Exception):
+    with pytest.raises(AauError):
         m(x[:1])                           # training batch of 1: same restriction as the reference's pooled-branch BN
     m.eval()

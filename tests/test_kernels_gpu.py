@@ -817,6 +817,11 @@ def test_image_pool_branch_kernels(ops, case):
     assert float((dx[:, :Cin].float().cpu() - dxe).abs().max()) < 1e-2 * float(dxe.abs().max()) + 1e-4
     with pytest.raises(RuntimeError):
         ops.poolbranch_dx(dz, wd, cpd, dx, xp, 17, Cin, Cout)
+    # one sample per channel: the reference's BatchNorm2d raises in training mode (pipeline:75-77), so does the library
+    with pytest.raises(RuntimeError):
+        ops.poolbranch_fwd(xd, xp, wf, cpf, z, dev(gamma), dev(beta), rmd, rvd, nbt, scale, shift, mean, invstd, 1, Cin, Cout)
+    with pytest.raises(RuntimeError):
+        ops.poolbranch_bwd(dyd, Cout + 16, z, xd, xp, dev(gamma), scale, shift, mean, invstd, dz, dgam, dbet, dw, 1, Cin, Cout)
 
 
 def test_igemm_multi_equals_the_separate_launches(ops):

@@ -97,3 +97,66 @@ def test_bucket_plan_is_contiguous_and_ordered():
     # channels_last parameter views: logical OIHW shape, K-contiguous physical order
     w = dict(model.named_parameters())["d2.0.block.0.weight"]
     assert tuple(w.shape) == (16, 8, 3, 3) and w.stride() == (72, 1, 24, 8)
+
+
+def _accum_worker(rank, world, port, q):
+    """DataParallel's part of gradient accumulation (model._NetFn hands it the kept gradient): the kept, already reduced
+    gradient is added only behind the bucket all-reduces of the new one."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import att_aspp_unet_amd as A
+        from att_aspp_unet_amd.engine import ParamStore
+        torch.manual_seed(0)
+        model = A.AttentionASPPUNet(base_c=8)
+        model.engine.store = ParamStore(model, torch.device("cpu"))
+        st = model.engine.store
+        dp = A.DataParallel(model)
+        assert model.engine.dp is dp and model.engine.bucket_cb is not None
+        marks = ("u1", "u2", "u3", "u4", "bridge", "d4", "d3", "d2", "d1")
+
+        def local(step, r):
+            return torch.randn(st.total, generator=torch.Generator().manual_seed(1000 * step + r))
+
+        def backward(step, keep):
+            dp.before_backward(keep)                 # what model._NetFn.backward does
+            st.gflat.copy_(local(step, rank))        # the engine rewrites the flat buffer ...
+            for mk in marks:                         # ... and fires the bucket marks on the way
+                model.engine.bucket_cb(mk)
+        backward(1, None)
+        dp.finish()
+        g1 = sum(local(1, r) for r in range(world))
+        assert torch.allclose(st.gflat, g1, atol=1e-6)
+        backward(2, st.gflat.clone())                # gradients not cleared: accumulate
+        dp.finish()
+        g2 = sum(local(2, r) for r in range(world))
+        assert torch.allclose(st.gflat, g1 + g2, atol=1e-5), float((st.gflat - g1 - g2).abs().max())
+        assert dp.pending is None
+        # a backward before finish() of the previous one is refused
+        backward(3, None)
+        try:
+            dp.before_backward(None)
+            ok = False
+        except RuntimeError:
+            ok = True
+        assert ok
+        dp.finish()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_accumulation_under_data_parallel_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

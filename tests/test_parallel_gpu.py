@@ -60,6 +60,29 @@ def _worker(rank, world, port, sd, x, y, q):
         step(xs, ys)
         torch.cuda.synchronize()
         out["flat2"] = st.flat.detach().cpu().numpy()
+        # gradient ACCUMULATION under data parallelism (autograd path): two backward calls without clearing the gradients
+        # must leave reduce(g_a) + reduce(g_b) on both ranks -- the kept gradient is added behind the bucket all-reduces
+        crit = A.build_criterion(Namespace(**ARGS), A.ComboLoss(), A.EdgeLoss())
+        xa, ya, xb, yb = xs[:2], ys[:2], xs[2:], ys[2:]
+
+        def grads(x_, y_, clear=True):
+            if clear:
+                opt.zero_grad()
+            crit(m(x_), y_).backward()
+            dp.finish()
+            torch.cuda.synchronize()
+            return st.gflat.detach().cpu().numpy().copy()
+        ga, gb = grads(xa, ya), grads(xb, yb)
+        grads(xa, ya)
+        out["acc"], out["ga"], out["gb"] = grads(xb, yb, clear=False), ga, gb
+        try:                                # a backward while the previous one's all-reduces are outstanding is refused
+            opt.zero_grad()
+            crit(m(xa), ya).backward()
+            crit(m(xb), yb).backward()
+            out["refused"] = False
+        except RuntimeError:
+            out["refused"] = True
+        dp.reducer.works, dp.reducer.fired, dp.pending = [], [], None
         q.put(out)
         dist.barrier()
         dist.destroy_process_group()
@@ -150,6 +173,11 @@ def test_engine_step_under_data_parallel_world2_matches_mean_of_per_rank_referen
         assert np.abs(res[r]["sd"][k] - ref_rm).max() < 4e-2 * np.abs(ref_rm).max() + 1e-4
     # 5. the dropout seed chain is mixed with the rank
     assert res[0]["drop_seed"] != res[1]["drop_seed"]
+    # 6. accumulation over two forward / backward pairs: reduce(g_a) + reduce(g_b), bit for bit, on both ranks
+    assert np.array_equal(res[0]["acc"], res[1]["acc"])
+    assert np.array_equal(res[0]["ga"], res[1]["ga"]) and not np.array_equal(res[0]["ga"], res[0]["gb"])
+    assert np.array_equal(res[0]["acc"], res[0]["ga"] + res[0]["gb"])
+    assert res[0]["refused"] and res[1]["refused"]
 
 
 def _train_worker(rank, world, port, out_dir, q):
@@ -218,3 +246,12 @@ def test_bench_runs_two_ranks_end_to_end():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["roofline"] is not None and d["cpu_baseline"] is None
+    # multi-GPU evidence fields: what the collective library connected, per-GPU rate, per-bucket overlap
+    c = d["config"]
+    assert c["rccl_ranks_seen"] == 2 and c["collective_backend"] == "gloo"
+    assert abs(c["images_per_sec_per_gpu"] * 2 - d["value"]) < 1e-6 * d["value"]
+    ov = c["overlap"]
+    assert set(ov["buckets"]) == {"u3", "u4", "bridge", "d4", "d1"}
+    for b in ov["buckets"].values():
+        assert b["mbytes"] > 0 and b["allreduce_ms_alone"] > 0 and b["backward_ms_behind_its_mark"] >= 0
+    assert ov["eager_step_ms_without_allreduce"] > 0 and ov["eager_step_ms_with_allreduce"] > 0

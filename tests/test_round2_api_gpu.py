@@ -294,6 +294,47 @@ def test_experiment_switches_do_not_change_the_result(A, switch, monkeypatch):
         assert float(cos) > 0.9999 and abs(float(ga.norm() / gb.norm()) - 1) < 1e-3
 
 
+@pytest.mark.parametrize("switch", ["AAU_NO_BNRED", "AAU_NO_IGEMM_MULTI", "AAU_NO_POOLBRANCH", "AAU_BRIDGE_WG_SIDE"])
+def test_default_on_fused_paths_against_their_off_switches_at_the_metric_shape(A, switch, monkeypatch):
+    """Whole-step A/B of the fused paths that are ON by default, at the shape where they engage (base_c 48, 8 x 512 x 512:
+    48-channel strip levels -> aau_conv_igemm_bnred; bridge 384 -> 768 on 8192 pixels = 256 wide tiles per branch ->
+    aau_conv_igemm_multi; batch <= 16 -> poolbranch kernels).  The multi-problem launch and the side-stream placement of
+    the grouped weight gradient run the same arithmetic (bitwise); the fused BatchNorm-backward sums and the image-pool
+    branch kernels add in another order."""
+    from att_aspp_unet_amd import synth
+    args = Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05)
+    x, y = synth.make_frames(8, 512, seed=5)
+    x, y = x.cuda(), y.cuda()
+
+    def run():
+        torch.manual_seed(3)
+        m = A.AttentionASPPUNet(base_c=48).cuda().train()
+        m.bridge.project[3].p = 0.0
+        step = A.TrainStep(m, A.FusedAdamW(m, lr=1e-3), args)
+        loss = float(step(x, y))
+        names = [op[2] for op in m._plan_for(x).fwd.ops + m._plan_for(x).bwd.ops]
+        g = m.engine.store.gflat.clone()
+        del step, m
+        torch.cuda.empty_cache()
+        return loss, g, names
+
+    la, ga, na = run()
+    assert "aau_conv_igemm_bnred" in na and "aau_conv_igemm_multi" in na and "aau_poolbranch_fwd" in na
+    monkeypatch.setenv(switch, "1")
+    lb, gb, nb = run()
+    off = {"AAU_NO_BNRED": "aau_conv_igemm_bnred", "AAU_NO_POOLBRANCH": "aau_poolbranch_fwd"}.get(switch)
+    if off:
+        assert off not in nb
+    if switch == "AAU_NO_IGEMM_MULTI":
+        assert nb.count("aau_conv_igemm_multi") < na.count("aau_conv_igemm_multi")
+    if switch in ("AAU_NO_IGEMM_MULTI", "AAU_BRIDGE_WG_SIDE"):
+        assert la == lb and torch.equal(ga, gb)
+    else:
+        assert abs(la - lb) <= 1e-5 * abs(la)
+        cos = torch.nn.functional.cosine_similarity(ga, gb, dim=0)
+        assert float(cos) > 0.9999 and abs(float(ga.norm() / gb.norm()) - 1) < 1e-3
+
+
 def test_gradient_accumulation_over_forward_backward_pairs(A):
     """torch semantics of ``.grad``: two forward / backward pairs without clearing the gradients in between ADD; clearing
     them (set_to_none, the default of optimisers and of Module.zero_grad) starts afresh.  Bitwise: g(a) + g(b)."""
