@@ -67,7 +67,8 @@ _SIGS = {
     "aau_conv_wgrad_ws_bytes": [C.POINTER(ConvDesc), C.POINTER(C.c_int64)],
     "aau_conv_wgrad_group_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_wgrad_group_member_ok": [C.POINTER(ConvDesc)],
-    "aau_conv_wgrad_group": [C.POINTER(ConvDesc), P, P, P, I, P],
+    "aau_conv_wgrad_group": [C.POINTER(ConvDesc), P, P, P, I, P, L, P],
+    "aau_conv_wgrad_group_queue_bytes": [],
     "aau_conv_igemm_multi_ok": [C.POINTER(ConvDesc), I],
     "aau_conv_igemm_multi": [C.POINTER(ConvDesc), P, P, P, P, P, I, P],
     "aau_conv_igemm_group_ok": [C.POINTER(ConvDesc), I],
@@ -181,6 +182,7 @@ def lib(kind: str | None = None) -> C.CDLL:
             fn.restype = C.c_int
         l.aau_bn_red_ws_bytes.restype = C.c_int64
         l.aau_conv_igemm_group_ws_bytes.restype = C.c_int64
+        l.aau_conv_wgrad_group_queue_bytes.restype = C.c_int64
         l.aau_bn_red_ws_bytes.argtypes = [C.c_int]
         _libs[kind] = l
     return l

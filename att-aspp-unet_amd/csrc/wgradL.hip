@@ -20,9 +20,20 @@
 //   * both operands stay [pixel][channel] in LDS as they arrive and are read transposed (ds_read_b64_tr_b16); rows are
 //     384 B, the 32-B granule is XOR-ed with bits 1-2 of the row on the SOURCE side of the LDS-DMA and on the read
 //     side, which makes the 8 rows of a 32-lane half hit 8 different 32-B bank windows (conflict free).
-// Tiles are ordered (problem, q-tile, tap, c-tile) and dealt to XCDs in contiguous chunks, so the 18 tiles that
-// stream the same dz columns share one L2.
+// Scheduling (round 4).  A tile's K-steps form a serial chain (counted wait -> barrier -> six LDS-DMA issues -> 24
+// transposed reads -> 36 MFMAs): ONE tile alone on a CU runs at 0.74 us per step, two co-resident tiles at 0.98 us per
+// step PAIR -- only a second workgroup on the CU overlaps the chain.  Tiles differ in length (dilation 18 at 32 x 32:
+// 44 % of the rows of an off-centre tap), and a plain grid of 336 tiles put two workgroups on 80 CUs and one on 176:
+// the launch ran at the pace of the doubly occupied CUs while the others idled after 0.4-1 tile.  Now the kernel is
+// PERSISTENT: 512 workgroups (two per CU, the LDS ring admits exactly two) pull tiles from work queues, longest first,
+// so every CU runs two chains until the queues are empty and the tail is made of the shortest tiles.  One queue per
+// XCD (the workgroup reads HW_REG_XCC_ID): the host deals (problem, q-tile) groups -- the 18 tiles that stream the same
+// dz columns -- to the eight queues by greedy longest-first bin packing, so a group's operand slices stay in one L2;
+// a workgroup whose queue is empty takes from the others'.  Placement only steers speed: any workgroup may run any
+// tile, every tile is run exactly once (one returning agent-scope atomic add per dequeue), tiles write disjoint blocks
+// of dw, so the result does not depend on who ran what.
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 
 namespace aau {
@@ -45,10 +56,16 @@ struct WLProb {
     unsigned src_bytes, dz_bytes;
 };
 
+constexpr int WL_MAXITEMS = 1024;      // tiles of one grouped launch (the order table travels in the kernel arguments)
+constexpr int WL_QSTRIDE = 16;         // ints between two queue heads (a 64-byte line each)
+
 struct WLArgs {
     WLProb p[WL_MAXP];
     int nprob, nitems;
     int flags;     // timing experiments only: 1 = no LDS-DMA, 2 = no LDS reads / MFMAs, 4 = no epilogue
+    int* queue;    // [8][WL_QSTRIDE]: head of the queue of XCD x at queue[x * WL_QSTRIDE]; ZERO when the launch starts
+    int bin_begin[9];                      // queue x holds order[bin_begin[x] .. bin_begin[x + 1])
+    unsigned short order[WL_MAXITEMS];     // tile ids, every queue longest tile first
 };
 
 // byte offset of (row, channel ch [multiple of 4]) inside a [32][192] bf16 tile
@@ -59,19 +76,36 @@ __device__ __forceinline__ int wl_off(int row, int ch) {
 // WL_NS = LDS ring slots (3: 72 KiB, two workgroups per CU).
 template <int WL_NS>
 __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];     // ring | 16 bytes: the dequeued tile id
     static_assert(WL_NS == 3, "the epilogue stages 96 x 192 fp32 through the 72-KiB ring");
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int wq = wave >> 1, wc = wave & 1;
+    int* const deq = (int*)(wl_smem + WL_NS * WL_STAGEB);
+    // HW_REG_XCC_ID (id 20), bits 3:0: which XCD this workgroup runs on -- picks the queue to start with, nothing else
+    const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+    int probe = 0;                 // queues this workgroup has found empty (thread 0's copy is the one that counts)
 
-    // XCD-aware bijective remap: consecutive logical ids (same problem / q-tile) share an XCD's L2
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k;
+  for (;;) {
+    // ---- next tile: own XCD's queue first, then the others' ----
+    if (tid == 0) {
+        int item = -1;
+        while (probe < 8) {
+            const int b = (xcc + probe) & 7;
+            const int n = a.bin_begin[b + 1] - a.bin_begin[b];
+            if (n > 0) {
+                const int i = __hip_atomic_fetch_add(a.queue + b * WL_QSTRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < n) { item = a.order[a.bin_begin[b] + i]; break; }
+            }
+            ++probe;
+        }
+        *deq = item;
     }
+    __syncthreads();               // also: every wave has finished reading the previous tile's staging area
+    const int bid = __builtin_amdgcn_readfirstlane(*deq);
+    __syncthreads();
+    if (bid < 0) break;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < WL_MAXP; ++i)
@@ -231,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
             islot = islot == 2 ? 0 : islot + 1;
         }
     }
-    if (a.flags & 4) return;
+    if (a.flags & 4) continue;
 
     // ---- epilogue: dw[q][tap][c0 ..] += D.  The accumulators go through LDS (96 q-rows x 192 fp32 = the whole ring)
     // so that global memory sees 16-B vectors along contiguous 768-B rows instead of 4-B pieces ----
@@ -262,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
             }
         }
     }
+  }   // next tile
 }
 
 }  // namespace aau
@@ -290,14 +325,31 @@ extern "C" int aau_conv_wgrad_group_ok(const aau_conv_desc* descs, int n) {
         if (!wl_ok(&descs[i])) return 0;
         tiles += (int64_t)((descs[i].Cout + WL_T - 1) / WL_T) * ((descs[i].Cin + WL_T - 1) / WL_T) * descs[i].KH * descs[i].KW;
     }
-    return tiles >= 160 ? 1 : 0;     // fewer tiles than ~2/3 of the CUs: the split-K kernels fill the chip better
+    // fewer tiles than ~2/3 of the CUs: the split-K kernels fill the chip better; more than the order table holds: not served
+    return tiles >= 160 && tiles <= WL_MAXITEMS ? 1 : 0;
+}
+
+extern "C" int64_t aau_conv_wgrad_group_queue_bytes(void) { return (int64_t)8 * WL_QSTRIDE * sizeof(int); }
+
+// valid K-steps of tile (problem P, tap): the kernel's own arithmetic
+static int wl_tile_steps(const WLProb& P, int tap) {
+    if (P.linear) return (P.M + 31) >> 5;
+    const int dy = (tap / P.KW) * P.dil - P.pad;
+    const int ylo = dy < 0 ? (-dy + P.stride - 1) / P.stride : 0;
+    int yhi = P.H - 1 - dy < 0 ? 0 : (P.H - 1 - dy) / P.stride + 1;
+    if (yhi > P.Ho) yhi = P.Ho;
+    return yhi > ylo ? (P.M / (P.Ho * P.Wo)) * (yhi - ylo) * (P.Wo >> 5) : 0;
 }
 
 extern "C" int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* const* srcs, const aau_bf16* const* dzs,
-                                    float* const* dws, int n, void* stream) {
+                                    float* const* dws, int n, int32_t* queue, int64_t queue_bytes, void* stream) {
     AAU_REQUIRE(descs && srcs && dzs && dws && n >= 1 && n <= WL_MAXP, "aau_conv_wgrad_group: bad args (n=%d, at most %d problems)", n, WL_MAXP);
+    AAU_REQUIRE(queue && queue_bytes >= aau_conv_wgrad_group_queue_bytes() && ((uintptr_t)queue & 3) == 0,
+                "aau_conv_wgrad_group: the work-queue heads need %lld zeroed bytes (aau_conv_wgrad_group_queue_bytes), got %lld",
+                (long long)aau_conv_wgrad_group_queue_bytes(), (long long)queue_bytes);
     WLArgs a;
     a.nprob = n;
+    a.queue = queue;
     int items = 0;
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -323,15 +375,62 @@ extern "C" int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* 
         bytes += 2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)P.M * d->Cout) + 4.0 * d->Cout * (double)P.T * d->Cin;
     }
     a.nitems = items;
+    AAU_REQUIRE(items <= WL_MAXITEMS, "aau_conv_wgrad_group: %d tiles, at most %d (aau_conv_wgrad_group_ok)", items, WL_MAXITEMS);
     a.flags = getenv("AAU_WL_FLAGS") ? atoi(getenv("AAU_WL_FLAGS")) : 0;
+    // ---- work queues: (problem, q-tile) groups dealt to the 8 XCD queues longest group first onto the lightest queue;
+    // inside a queue longest tile first (stable: tiles of a group with equal length stay together) ----
+    struct Item { unsigned short id; int steps; int group; };
+    struct Group { int first, count; int64_t steps; };
+    Item it[WL_MAXITEMS];
+    Group gr[WL_MAXITEMS];
+    int ni = 0, ng = 0;
+    for (int i = 0; i < n; ++i) {
+        const WLProb& P = a.p[i];
+        for (int tq = 0; tq < P.ntq; ++tq) {
+            Group g{ni, 0, 0};
+            for (int tap = 0; tap < P.T; ++tap) {
+                const int steps = wl_tile_steps(P, tap);
+                if (steps == 0) continue;                      // the tap never meets the image: nothing to add
+                for (int tc = 0; tc < P.ntc; ++tc) {
+                    it[ni++] = Item{(unsigned short)(P.item_begin + (tq * P.T + tap) * P.ntc + tc), steps, ng};
+                    g.steps += steps; ++g.count;
+                }
+            }
+            if (g.count) gr[ng++] = g;
+        }
+    }
+    if (ni == 0) return AAU_OK;
+    int gorder[WL_MAXITEMS];
+    for (int i = 0; i < ng; ++i) gorder[i] = i;
+    std::stable_sort(gorder, gorder + ng, [&](int x, int y) { return gr[x].steps > gr[y].steps; });
+    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int bin_of[WL_MAXITEMS];
+    for (int k = 0; k < ng; ++k) {
+        int b = 0;
+        for (int x = 1; x < 8; ++x) if (load[x] < load[b]) b = x;
+        bin_of[gorder[k]] = b;
+        load[b] += gr[gorder[k]].steps;
+    }
+    int pos = 0;
+    for (int b = 0; b < 8; ++b) {
+        a.bin_begin[b] = pos;
+        int idx[WL_MAXITEMS], m = 0;
+        for (int i = 0; i < ni; ++i) if (bin_of[it[i].group] == b) idx[m++] = i;
+        std::stable_sort(idx, idx + m, [&](int x, int y) { return it[x].steps > it[y].steps; });
+        for (int i = 0; i < m; ++i) a.order[pos++] = it[idx[i]].id;
+    }
+    a.bin_begin[8] = pos;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(1, flops, s);
     prof_tag("wgradL<192,192> grouped", bytes);
+    constexpr size_t lds = 3 * WL_STAGEB + 16;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)wgradL_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WL_STAGEB);
+        hipFuncSetAttribute((const void*)wgradL_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((wgradL_kernel<3>), dim3((unsigned)items), dim3(256), 3 * WL_STAGEB, s, a);
+    // two workgroups per CU (the ring admits exactly two); fewer tiles than that: one workgroup per tile
+    const int grid = ni < 512 ? ni : 512;
+    hipLaunchKernelGGL((wgradL_kernel<3>), dim3((unsigned)grid), dim3(256), lds, s, a);
     return check_launch("aau_conv_wgrad_group");
 }

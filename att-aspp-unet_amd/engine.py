@@ -890,7 +890,9 @@ class Plan:
                     wg_side = eng.bridge_wg_side
                     if wg_side:
                         b.fork()
-                    b.add("aau_conv_wgrad_group", *pack, side=wg_side)
+                    # heads of the launch's work queues: words of the arena that begin_backward clears every step
+                    qws = self.red_arena.take(ops.wgrad_group_queue_words())
+                    b.add("aau_conv_wgrad_group", *pack, qws, qws.numel() * 4, side=wg_side)
                 else:
                     for dwd, src, dz_, dw_, lab in wg:
                         b.label = lab

@@ -141,10 +141,19 @@ def conv_wgrad_group_ok(descs, lone_ok: bool = False) -> bool:
     return bool(fn("aau_conv_wgrad_group_ok")((ConvDesc * n)(*descs), n))
 
 
-def conv_wgrad_group(descs, srcs, dzs, dws):
-    """dw_i += weight gradient of problem i, all problems in one launch (see include/aau.h)."""
+def wgrad_group_queue_words() -> int:
+    """int32 words of the work-queue heads of aau_conv_wgrad_group (the caller zeroes them before every call)."""
+    return int(fn("aau_conv_wgrad_group_queue_bytes")()) // 4
+
+
+def conv_wgrad_group(descs, srcs, dzs, dws, queue=None):
+    """dw_i += weight gradient of problem i, all problems in one launch (see include/aau.h).  ``queue``: zeroed int32
+    tensor of ``wgrad_group_queue_words()`` words (a fresh one is made when omitted)."""
     da, sa, za, wa, n = wgrad_group_args(descs, srcs, dzs, dws)
-    check(fn("aau_conv_wgrad_group")(da, sa, za, wa, n, _stream()), "aau_conv_wgrad_group")
+    if queue is None:
+        queue = torch.zeros(wgrad_group_queue_words(), dtype=torch.int32, device=dws[0].device)
+    check(fn("aau_conv_wgrad_group")(da, sa, za, wa, n, _p(queue), queue.numel() * queue.element_size(), _stream()),
+          "aau_conv_wgrad_group")
 
 
 def igemm_group_args(descs, srcs, wpks, dst, ws):

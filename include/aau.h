@@ -160,8 +160,13 @@ int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes);
 /* enough to fill the chip (otherwise use aau_conv_wgrad per problem).                                  */
 int aau_conv_wgrad_group_member_ok(const aau_conv_desc* d);   /* one problem's eligibility (the group needs >= 160 tiles in all) */
 int aau_conv_wgrad_group_ok(const aau_conv_desc* descs, int n);
+/* The launch is persistent: 512 workgroups pull tiles, longest first, from eight work queues (one per XCD); `queue`   */
+/* holds their heads: aau_conv_wgrad_group_queue_bytes() bytes that the CALLER has zeroed on the stream before the   */
+/* call (every call: the kernel leaves them advanced).                                                               */
+int64_t aau_conv_wgrad_group_queue_bytes(void);
 int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* const* srcs,
-                         const aau_bf16* const* dzs, float* const* dws, int n, void* stream);
+                         const aau_bf16* const* dzs, float* const* dws, int n, int32_t* queue, int64_t queue_bytes,
+                         void* stream);
 
 /* Several independent convolutions in ONE launch: problem i is exactly aau_conv_igemm(&descs[i], srcs[i], wpks[i],      */
 /* dsts[i], no bias / affine, stats[i]) -- its own weights, dilation, destination and statistics.  Built for the forward   */
