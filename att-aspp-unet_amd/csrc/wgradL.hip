@@ -6,32 +6,24 @@
 // dilated 3x3 branches + 1x1 + 3840 -> 768 projection) the generic kernel (wgrad.hip: 96 x 96 tiles, 18 MFMAs per
 // wave between two vmcnt(0) barriers, 8-way split-K with 85 MB of partial slabs per branch) ran at 17-19 % of the
 // MFMA peak.  Here
-//   * a workgroup owns a 192(q) x 192(c) tile of ONE tap (4 waves x 96 x 96 = 36 accumulator tiles each): 96 FLOP
-//     per staged byte instead of 48, 36 MFMAs per wave between barriers;
-//   * the five problems are tiled into one grid (304 tiles at base_c 48), so every tile runs the FULL pixel range:
-//     no split-K, no slabs, no reduce pass, results bitwise reproducible;
+//   * a TILE is 192(q) x 192(c) outputs of ONE tap over the FULL pixel range (336 tiles at base_c 48 with the deepest
+//     ConvTranspose2d riding along): no split-K, no slabs, no reduce pass, results bitwise reproducible;
 //   * K-steps are 32-pixel row segments: a step whose source row (y + dy) lies outside the image is skipped as a
-//     whole (dilation 18 at 32 x 32: 56 % of the steps of the off-centre tap rows);
-//   * 3-slot LDS ring filled by buffer_load ... lds with a counted s_waitcnt vmcnt(6) + one raw s_barrier per step
-//     (the next step's tiles stay in flight across the barrier), 72 KiB -> two workgroups per CU.  Measured on the
-//     way (MI355X, 256 tiles): a 6-slot ring and an extra wave that warms L2 eight steps ahead changed nothing --
-//     the step time is the serial sum of LDS-DMA issue (~500 cycles per wave), transposed reads + MFMAs (~850) and
-//     loop overhead, which two workgroups per CU overlap;
-//   * both operands stay [pixel][channel] in LDS as they arrive and are read transposed (ds_read_b64_tr_b16); rows are
-//     384 B, the 32-B granule is XOR-ed with bits 1-2 of the row on the SOURCE side of the LDS-DMA and on the read
-//     side, which makes the 8 rows of a 32-lane half hit 8 different 32-B bank windows (conflict free).
-// Scheduling (round 4).  A tile's K-steps form a serial chain (counted wait -> barrier -> six LDS-DMA issues -> 24
-// transposed reads -> 36 MFMAs): ONE tile alone on a CU runs at 0.74 us per step, two co-resident tiles at 0.98 us per
-// step PAIR -- only a second workgroup on the CU overlaps the chain.  Tiles differ in length (dilation 18 at 32 x 32:
-// 44 % of the rows of an off-centre tap), and a plain grid of 336 tiles put two workgroups on 80 CUs and one on 176:
-// the launch ran at the pace of the doubly occupied CUs while the others idled after 0.4-1 tile.  Now the kernel is
-// PERSISTENT: 512 workgroups (two per CU, the LDS ring admits exactly two) pull tiles from work queues, longest first,
-// so every CU runs two chains until the queues are empty and the tail is made of the shortest tiles.  One queue per
-// XCD (the workgroup reads HW_REG_XCC_ID): the host deals (problem, q-tile) groups -- the 18 tiles that stream the same
-// dz columns -- to the eight queues by greedy longest-first bin packing, so a group's operand slices stay in one L2;
-// a workgroup whose queue is empty takes from the others'.  Placement only steers speed: any workgroup may run any
-// tile, every tile is run exactly once (one returning agent-scope atomic add per dequeue), tiles write disjoint blocks
-// of dw, so the result does not depend on who ran what.
+//     whole (dilation 18 at 32 x 32: 56 % of the steps of the off-centre tap rows), so tiles differ in length;
+//   * both operands stay [pixel][channel] in LDS as the LDS-DMA delivers them and are read transposed
+//     (ds_read_b64_tr_b16); rows are 384 B, the 32-B granule is XOR-ed with bits 1-2 of the row on the SOURCE side of
+//     the DMA and on the read side: the 8 rows of a 32-lane half hit 8 different 32-B bank windows (conflict free).
+// Rounds 2-3 ran one four-wave workgroup per tile, two per CU.  A tile's K-steps are a serial chain (counted wait ->
+// barrier -> six LDS-DMA issues per wave -> 24 transposed reads -> 36 MFMAs) that only a second chain on the CU
+// overlaps: one tile alone took 0.74-0.9 us per step, two co-resident ones 0.98-1.1 us per step pair -- but then the
+// scheduling unit is HALF a CU, and 336 tiles of unequal length cannot be dealt evenly to 512 half-CUs that all start at
+// once: 80 CUs got two tiles, 176 one, and the launch (253-284 us) ran at the pace of the former.  Round 4
+// (wgradL_pp_kernel below): ONE persistent eight-wave workgroup per CU whose two four-wave groups work on the same
+// tile half a step apart, tiles pulled from per-XCD work queues longest first: 201-204 us for the same launch.
+// Measured on the way (profiles/NOTES.md): an eight-wave workgroup in lockstep (48 x 96 per wave, 6-slot ring) is no
+// faster per tile than four waves; with the multiply halves removed a step still cost 0.48 us in address arithmetic
+// and branches around the DMA issues (now scalar offsets: 0.37 us, the LDS-DMA issue itself); the order of the 24
+// reads (first MFMA after 4 instead of 18) and a single chip-wide queue change nothing.
 #include <stdlib.h>
 #include <algorithm>
 #include "common.h"
@@ -73,22 +65,35 @@ __device__ __forceinline__ int wl_off(int row, int ch) {
     return row * WL_ROWB + ((((ch >> 4) ^ ((row >> 1) & 3))) << 5) + (ch & 15) * 2;
 }
 
-// WL_NS = LDS ring slots (3: 72 KiB, two workgroups per CU).
-template <int WL_NS>
-__global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];     // ring | 16 bytes: the dequeued tile id
-    static_assert(WL_NS == 3, "the epilogue stages 96 x 192 fp32 through the 72-KiB ring");
+#define WL_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define WL_FRAG(lo, hi) __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ping-pong form: ONE persistent workgroup per CU, eight waves in two four-wave groups that work on the SAME tile.
+// Group g takes the tile's K-steps g, g + 2, ... with its own 3-slot ring and its own 96 x 96 accumulators per wave
+// (the layout of the four-wave form), and the two groups run HALF A STEP APART: between the two barriers of a tick one
+// group issues its LDS-DMA and reads its fragments (the "load" half) while the other one multiplies (36 MFMAs per wave),
+// then they swap.  Why: a tile's step is a serial chain (wait -> barrier -> DMA issue -> transposed reads -> MFMAs) that
+// only a second, independent chain on the CU overlaps -- the four-wave form gets that from a second WORKGROUP, but then
+// a tile is the scheduling unit of HALF a CU and 336 tiles of unequal length cannot be dealt evenly to 512 half-CUs
+// that all start at once (80 CUs got two tiles, 176 one: the launch ran at the pace of the former).  Here the unit is a
+// whole CU, tiles outnumber the 256 workgroups, and the queues (longest first) balance them.  At the end of a tile group
+// 1's accumulators are added to group 0's through the staging area of the epilogue, in a fixed order.
+__global__ __launch_bounds__(512, 2) void wgradL_pp_kernel(const WLArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl_smem[];     // [2 groups][3 slots] | 16 bytes
+    constexpr int NS = 3, NPW = 6;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int wq = wave >> 1, wc = wave & 1;
-    int* const deq = (int*)(wl_smem + WL_NS * WL_STAGEB);
-    // HW_REG_XCC_ID (id 20), bits 3:0: which XCD this workgroup runs on -- picks the queue to start with, nothing else
+    const int grp = wave >> 2, wl = wave & 3;
+    const int wq = wl >> 1, wc = wl & 1;
+    const int gtid = tid & 255;
+    unsigned char* const ring = wl_smem + grp * NS * WL_STAGEB;
+    int* const deq = (int*)(wl_smem + 2 * NS * WL_STAGEB);
     const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
-    int probe = 0;                 // queues this workgroup has found empty (thread 0's copy is the one that counts)
+    int probe = 0;
 
   for (;;) {
-    // ---- next tile: own XCD's queue first, then the others' ----
     if (tid == 0) {
         int item = -1;
         while (probe < 8) {
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
         }
         *deq = item;
     }
-    __syncthreads();               // also: every wave has finished reading the previous tile's staging area
+    __syncthreads();
     const int bid = __builtin_amdgcn_readfirstlane(*deq);
     __syncthreads();
     if (bid < 0) break;
@@ -110,8 +115,7 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
 #pragma unroll
     for (int i = 1; i < WL_MAXP; ++i)
         if (i < a.nprob && a.p[i].item_begin <= bid) pi = i;
-    const WLProb P = a.p[pi];      // by value: one batch of scalar loads, then SGPRs (a reference re-reads the kernarg
-                                   // segment inside the K loop: 0.3 us per step)
+    const WLProb P = a.p[pi];
     int local = bid - P.item_begin;
     const int tc = local % P.ntc; local /= P.ntc;
     const int tap = local % P.T;
@@ -123,9 +127,7 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)P.src, 0, P.src_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    // ---- K-steps = 32-pixel segments of output rows; only rows whose source row y*stride+dy is inside the image ----
-    // (linear problems: one "row" of M pixels per launch)
-    const int segs = P.linear ? (P.M + 31) >> 5 : P.Wo >> 5;          // steps per row
+    const int segs = P.linear ? (P.M + 31) >> 5 : P.Wo >> 5;
     int ylo = 0, yhi = 1, nimg = 1;
     if (!P.linear) {
         ylo = dy < 0 ? (-dy + P.stride - 1) / P.stride : 0;
@@ -134,19 +136,18 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
         nimg = P.M / (P.Ho * P.Wo);
     }
     const int total = yhi > ylo ? nimg * (yhi - ylo) * segs : 0;      // valid K-steps of this tile
+    const int ticks = (total + 1) >> 1;                               // steps of either group (group 1's last may be empty)
 
-    // ---- the three 16-B pieces per operand this thread stages every K-step ----
-    // piece p = (i*4 + wave)*64 + lane -> LDS offset p*16 (lane-linear); row = p / 24, physical half-granule p % 24
-    unsigned ybase[3], xbase[3];   // byte offset of (row, channel) relative to the step's first pixel (may wrap below 0)
-    int prow[3], xcol[3];          // xcol: source column of the row relative to x0*stride
-    bool yok[3], xok[3];           // channel inside the tensor (tile tails); xok also: column inside the image when
-                                   // the row has a single segment (then it does not depend on the step)
+    // the three 16-B pieces per operand this thread stages every K-step of its group (the four-wave form's roles)
+    unsigned ybase[3], xbase[3];
+    int prow[3], xcol[3], pch[3];
+    bool yok[3], xok[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int p = (i * 4 + wave) * 64 + lane;
+        const int p = (i * 4 + wl) * 64 + lane;
         const int row = p / 24, hg = p - row * 24;
         const int ch = ((((hg >> 1) ^ ((row >> 1) & 3)) << 1) | (hg & 1)) * 8;
-        prow[i] = row;
+        prow[i] = row; pch[i] = ch;
         yok[i] = q0 + ch < P.Cout;
         xok[i] = c0 + ch < P.Cin;
         ybase[i] = (unsigned)((row * P.dst_pitch + q0 + ch) * 2);
@@ -154,16 +155,51 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
         xbase[i] = (unsigned)(((P.linear ? row : xcol[i]) * P.src_pitch + c0 + ch) * 2);
         if (!P.linear && segs == 1) xok[i] = xok[i] && (unsigned)xcol[i] < (unsigned)P.W;
     }
-    const bool ragged = (P.M & 31) != 0;       // only linear problems can end inside a step
+    const bool ragged = (P.M & 31) != 0;
     const bool multiseg = !P.linear && segs > 1;
+    // Fast issue path (every step of the tile is a whole 32-pixel segment of a single-segment row: the bridge's shapes):
+    // the per-lane part of a piece's address -- with every mask folded in as an out-of-range offset -- is a constant of
+    // the tile, the step only changes the SCALAR offset of the instruction, so a K-step issues its six LDS-DMAs with no
+    // vector arithmetic (the general path below spent ~150 cycles per piece on predicates and branches: with the
+    // multiply halves removed a step still took 0.48 us).  The x resource starts `shiftb` bytes in front of the tensor
+    // so that the scalar part stays non-negative for taps that reach to the left (dx < 0).
+    const bool fast = !ragged && !multiseg;
+    const unsigned shiftb = (unsigned)(P.pad * P.src_pitch * 2);
+    const __amdgpu_buffer_rsrc_t rsXs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)P.src - shiftb), 0,
+                                                                          P.src_bytes + shiftb, 0x00020000);
+    unsigned vy[3], vx[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        vy[i] = yok[i] ? ybase[i] : OOB;
+        vx[i] = xok[i] ? (unsigned)(((P.linear ? prow[i] : prow[i] * P.stride) * P.src_pitch + c0 + pch[i]) * 2) : OOB;
+    }
 
-    // issue iterator (n, y, x0): plain counters, no validity tests inside the loop
-    int in_ = 0, iy = ylo, ix0 = 0, issued = 0;
+    // issue iterator of this group over the tile's steps grp, grp + 2, ...
+    int in_ = 0, iy = ylo, ix0 = 0, istep = 0;
+    auto adv = [&]() {
+        ++istep;
+        ix0 += 32;
+        if (ix0 >= (P.linear ? P.M : P.Wo)) { ix0 = 0; if (++iy == yhi) { iy = ylo; ++in_; } }
+    };
+    if (grp) adv();
     auto issue = [&](int slot) {
-        unsigned char* sY = wl_smem + slot * WL_STAGEB;
+        unsigned char* sY = ring + slot * WL_STAGEB;
         unsigned char* sX = sY + WL_TILEB;
-        const bool live = issued < total && !(a.flags & 1);     // past the end: zero rows (keeps the vmcnt count constant)
+        const bool live = istep < total && !(a.flags & 1);      // past the end: zero rows (keeps the vmcnt count constant)
         const int m0 = P.linear ? ix0 : (in_ * P.Ho + iy) * P.Wo + ix0;
+        if (fast) {
+            const unsigned sy = (unsigned)m0 * (unsigned)(P.dst_pitch * 2);
+            const unsigned sx = P.linear ? (unsigned)m0 * (unsigned)(P.src_pitch * 2)
+                                         : (unsigned)(((in_ * P.H + iy * P.stride + dy) * P.W + ix0 * P.stride + dx) * P.src_pitch * 2) + shiftb;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY + (i * 4 + wl) * 1024), 16, (int)(live ? vy[i] : OOB), (int)sy, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsXs, LDS_PTR(sX + (i * 4 + wl) * 1024), 16, (int)(live ? vx[i] : OOB), (int)sx, 0, 0);
+            adv(); adv();
+            return;
+        }
         const unsigned yoff = (unsigned)m0 * (unsigned)(P.dst_pitch * 2);
         const int xs0 = ix0 * P.stride;
         const unsigned xoff = P.linear ? (unsigned)m0 * (unsigned)(P.src_pitch * 2)
@@ -173,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
             bool ok = live && yok[i];
             if (ragged) ok = ok && m0 + prow[i] < P.M;
             const unsigned v = ok ? ybase[i] + yoff : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY + (i * 4 + wl) * 1024), 16, (int)v, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -181,11 +217,9 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
             if (ragged) ok = ok && m0 + prow[i] < P.M;
             if (multiseg) ok = ok && (unsigned)(xs0 + xcol[i]) < (unsigned)P.W;
             const unsigned v = ok ? xbase[i] + xoff : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX + (i * 4 + wl) * 1024), 16, (int)v, 0, 0, 0);
         }
-        ++issued;
-        ix0 += 32;
-        if (ix0 >= (P.linear ? P.M : P.Wo)) { ix0 = 0; if (++iy == yhi) { iy = ylo; ++in_; } }
+        adv(); adv();
     };
 
     f32x4 acc[6][6];
@@ -194,8 +228,6 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // transposed-read addressing: lane 4*rq+p of a 16-lane group supplies row rq, columns 4p..4p+3; group g16 owns
-    // rows 4*g16 .. 4*g16+3 (lo) and 16 + the same (hi):  k = 8*g16 + 4*h + e  <->  pixel 16*h + 4*g16 + e
     const int g16 = lane >> 4, li = lane & 15;
     const int rrow = 4 * g16 + (li >> 2), cp = (li & 3) * 4;
     int yoffs[6], xoffs[6];
@@ -204,78 +236,86 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
         yoffs[i] = wl_off(rrow, wq * 96 + i * 16 + cp);
         xoffs[i] = WL_TILEB + wl_off(rrow, wc * 96 + i * 16 + cp);
     }
-    // The transposed reads are inline asm: hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_tr BUILTIN whenever an
-    // LDS-DMA is in flight (it cannot tell the ring slots apart), which serialises the whole pipeline; it does not see
-    // inside an asm statement, so the counted vmcnt above the barrier is the only wait.  The waits for the reads are
-    // explicit and name every destination ("+v"), which keeps the MFMAs below them (guide 5.7, form ii).
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)wl_smem;
-#define WL_TR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
-#define WL_FRAG(lo, hi) __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)ring;
+    // multiply half of a step: the 24 transposed reads of slot `slot` and the 36 MFMAs.  While this group multiplies, the
+    // other one only issues DMAs, so nothing else feeds the matrix pipe during the reads' latency: the reads are issued
+    // in "growing square" order (A0 B0 A1 B1 ... A5 B5; LDS returns in order) and the products max(i, j) = k start as
+    // soon as A_k and B_k are back -- the first MFMA after 4 of the 24 reads instead of 18.
     auto compute = [&](int slot) {
         if (a.flags & 2) return;
         const unsigned base = lds0 + slot * WL_STAGEB;
         u32x2 alo[6], ahi[6], blo[6], bhi[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const unsigned ad = base + yoffs[i];
-            WL_TR(alo[i], ad, 0);
-            WL_TR(ahi[i], ad, 6144);          // 16 rows further: 16 * WL_ROWB
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const unsigned ad = base + xoffs[j];
-            WL_TR(blo[j], ad, 0);
-            WL_TR(bhi[j], ad, 6144);
-        }
-        // LDS returns in order: all but the last 6 reads (blo/bhi[3..5]) are back
-        asm volatile("s_waitcnt lgkmcnt(6)"
-                     : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(alo[4]), "+v"(alo[5]), "+v"(ahi[0]),
-                       "+v"(ahi[1]), "+v"(ahi[2]), "+v"(ahi[3]), "+v"(ahi[4]), "+v"(ahi[5]), "+v"(blo[0]), "+v"(blo[1]),
-                       "+v"(blo[2]), "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]));
-        bf16x8 af[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) af[i] = WL_FRAG(alo[i], ahi[i]);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const bf16x8 bf = WL_FRAG(blo[j], bhi[j]);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc[i][j] = AAU_MFMA16(af[i], bf, acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[3]), "+v"(blo[4]), "+v"(blo[5]), "+v"(bhi[3]), "+v"(bhi[4]), "+v"(bhi[5]));
-#pragma unroll
-        for (int j = 3; j < 6; ++j) {
-            const bf16x8 bf = WL_FRAG(blo[j], bhi[j]);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc[i][j] = AAU_MFMA16(af[i], bf, acc[i][j], 0, 0, 0);
-        }
+#define WL_READ(K)                                                                                                        \
+        { const unsigned ay = base + yoffs[K], ax = base + xoffs[K];                                                      \
+          WL_TR(alo[K], ay, 0); WL_TR(ahi[K], ay, 6144); WL_TR(blo[K], ax, 0); WL_TR(bhi[K], ax, 6144); }
+        bf16x8 af[6], bf[6];
+#define WL_STAGE(K, CNT)                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(alo[K]), "+v"(ahi[K]), "+v"(blo[K]), "+v"(bhi[K]));               \
+        af[K] = WL_FRAG(alo[K], ahi[K]);                                                                                  \
+        bf[K] = WL_FRAG(blo[K], bhi[K]);                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < K; ++i) acc[i][K] = AAU_MFMA16(af[i], bf[K], acc[i][K], 0, 0, 0);          \
+        _Pragma("unroll") for (int j = 0; j <= K; ++j) acc[K][j] = AAU_MFMA16(af[K], bf[j], acc[K][j], 0, 0, 0);      \
+        __builtin_amdgcn_sched_barrier(0);      /* hipcc would sink every MFMA below the last wait (guide 5.4 rule 18) */
+        // (lgkmcnt is a 4-bit field: at most 15 can be named, so the last two read groups follow the first two stages)
+        WL_READ(0) WL_READ(1) WL_READ(2) WL_READ(3)
+        WL_STAGE(0, 12)
+        WL_READ(4)
+        WL_STAGE(1, 12)
+        WL_READ(5)
+        WL_STAGE(2, 12)
+        WL_STAGE(3, 8)
+        WL_STAGE(4, 4)
+        WL_STAGE(5, 0)
+#undef WL_READ
+#undef WL_STAGE
     };
 
-    // ---- pipeline: two steps in flight; every step issues 6 LDS-DMA per thread (steps past the end load zero rows), so
-    // the wait is one constant: all but the youngest 6 have landed ----
-    if (total > 0) {
-        issue(0);
-        issue(1);
-        int slot = 0, islot = 2;
-        for (int t = 0; t < total; ++t) {
+    // ---- ticks: two barriers each.  Between b1 and b2 group 0 multiplies its step t (transposed reads + 36 MFMAs per
+    // wave) while group 1 issues the LDS-DMA of its step t + 2 and waits for its step t; between b2 and the next b1 they
+    // swap (group 0 issues step t + 2, waits for step t + 1).  RAW: a group's waves wait (all but their youngest 6 DMAs
+    // landed) in front of the barrier that opens their multiply half.  WAR: a DMA goes into the slot whose reads ended at
+    // least a whole tick earlier (3 slots per group). ----
+    if (ticks > 0) {
+        if (grp == 0) {
+            issue(0);
+            issue(1);
+            int slot = 0, islot = 2;
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(islot);                       // the slot read in the previous iteration
-            compute(slot);
-            slot = slot == 2 ? 0 : slot + 1;
-            islot = islot == 2 ? 0 : islot + 1;
+            for (int t = 0; t < ticks; ++t) {
+                __builtin_amdgcn_s_barrier();               // b1
+                compute(slot);
+                __builtin_amdgcn_s_barrier();               // b2
+                issue(islot);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                slot = slot == 2 ? 0 : slot + 1;
+                islot = islot == 2 ? 0 : islot + 1;
+            }
+        } else {
+            issue(0);
+            issue(1);
+            int slot = 0, islot = 2;
+            for (int t = 0; t < ticks; ++t) {
+                __builtin_amdgcn_s_barrier();               // b1
+                issue(islot);                               // step t + 2, into the slot of step t - 1 (read before b1)
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // step t has landed; t + 1 and t + 2 stay in flight
+                __builtin_amdgcn_s_barrier();               // b2
+                compute(slot);
+                slot = slot == 2 ? 0 : slot + 1;
+                islot = islot == 2 ? 0 : islot + 1;
+            }
         }
     }
     if (a.flags & 4) continue;
 
-    // ---- epilogue: dw[q][tap][c0 ..] += D.  The accumulators go through LDS (96 q-rows x 192 fp32 = the whole ring)
-    // so that global memory sees 16-B vectors along contiguous 768-B rows instead of 4-B pieces ----
+    // ---- epilogue: dw[q][tap][c0 ..] += D0 + D1 through LDS (96 q-rows x 192 fp32 per half): group 1 stores its
+    // accumulators, group 0 adds its own on top (same lane -> element map: every element is touched by one thread of each
+    // group), then all 512 threads copy out 16-B vectors along contiguous 768-B rows ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* stg = (float*)wl_smem;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
-        if (wq == h) {
-            // acc[i][j][r] = D[q = q0 + wq*96 + i*16 + 4*g16 + r][c = c0 + wc*96 + j*16 + li]
+        if (wq == h && grp == 1) {
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -284,7 +324,16 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
                     for (int r = 0; r < 4; ++r) stg[(i * 16 + 4 * g16 + r) * WL_T + wc * 96 + j * 16 + li] = acc[i][j][r];
         }
         __syncthreads();
-        for (int v = tid; v < 96 * 48; v += 256) {
+        if (wq == h && grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg[(i * 16 + 4 * g16 + r) * WL_T + wc * 96 + j * 16 + li] += acc[i][j][r];
+        }
+        __syncthreads();
+        for (int v = tid; v < 96 * 48; v += 512) {
             const int row = v / 48, c4 = (v - row * 48) * 4;
             const int q = q0 + h * 96 + row, c = c0 + c4;
             if (q < P.Cout && c < P.Cin) {
@@ -296,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void wgradL_kernel(const WLArgs a) {
             }
         }
     }
+    (void)gtid;
   }   // next tile
 }
 
@@ -423,14 +473,13 @@ extern "C" int aau_conv_wgrad_group(const aau_conv_desc* descs, const aau_bf16* 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(1, flops, s);
     prof_tag("wgradL<192,192> grouped", bytes);
-    constexpr size_t lds = 3 * WL_STAGEB + 16;
+    constexpr size_t lds = (size_t)6 * WL_STAGEB + 16;       // [2 groups][3 slots] | the dequeued tile id
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)wgradL_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)wgradL_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    // two workgroups per CU (the ring admits exactly two); fewer tiles than that: one workgroup per tile
-    const int grid = ni < 512 ? ni : 512;
-    hipLaunchKernelGGL((wgradL_kernel<3>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    // one persistent workgroup per CU; fewer tiles than CUs: one workgroup per tile
+    hipLaunchKernelGGL(wgradL_pp_kernel, dim3((unsigned)(ni < 256 ? ni : 256)), dim3(512), lds, s, a);
     return check_launch("aau_conv_wgrad_group");
 }

@@ -33,25 +33,35 @@ def run(names, reps=20):
     ps = [prob(k, i) for i, k in enumerate(names)]
     descs, srcs, dzs, dws = zip(*ps)
     tiles = sum(((d.Cout + 191) // 192) * ((d.Cin + 191) // 192) * d.KH * d.KW for d in descs)
-    for _ in range(3):
-        ops.conv_wgrad_group(list(descs), list(srcs), list(dzs), list(dws))
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        ops.conv_wgrad_group(list(descs), list(srcs), list(dzs), list(dws))
-    e1.record()
-    torch.cuda.synchronize()
-    print(f"{'+'.join(names):50s} tiles {tiles:4d}  {e0.elapsed_time(e1) / reps * 1e3:7.1f} us", flush=True)
+    q = torch.zeros(ops.wgrad_group_queue_words(), dtype=torch.int32, device=dev)
+    out = []
+    for form in FORMS:
+        os.environ["AAU_WL_FORM"] = str(form)
+        ts = []
+        for rep in range(3):
+            for _ in range(3):
+                q.zero_()
+                ops.conv_wgrad_group(list(descs), list(srcs), list(dzs), list(dws), q)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tot = 0.0
+            for _ in range(reps):
+                q.zero_()
+                e0.record()
+                ops.conv_wgrad_group(list(descs), list(srcs), list(dzs), list(dws), q)
+                e1.record()
+                torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            ts.append(tot / reps * 1e3)
+        out.append(f"form {form}: {min(ts):7.1f}")
+    print(f"{'+'.join(names):46s} tiles {tiles:4d}  " + "   ".join(out) + "  us", flush=True)
 
 
+FORMS = [int(f) for f in os.environ.get("WL_FORMS", "0,1,2").split(",")]
 run(["proj"])
-run(["proj", "proj"])
-run(["proj", "proj", "proj"])
 run(["proj"] * 4)
 run(["proj"] * 6)
 run(["dil18"])
-run(["dil6"])
 run(["dil6", "dil12", "dil18"])
 run(["1x1", "dil6", "dil12", "dil18", "proj"])
 run(["up", "1x1", "dil6", "dil12", "dil18", "proj"])
