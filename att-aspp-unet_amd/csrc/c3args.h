@@ -26,6 +26,10 @@ struct C3Args {
     const float* bn_shift = nullptr;
     const float* bn_mean = nullptr;
     const float* bn_invstd = nullptr;
+    // conv3x3s only (aau_conv_igemm_bnin): src is the RAW conv output z of the producing BatchNorm -> ReLU layer; the kernel
+    // applies y = relu(z * in_scale + in_shift) in LDS behind the landing fill (the activation is never written to memory)
+    const float* in_scale = nullptr;
+    const float* in_shift = nullptr;
     int nowide;          // experiment (AAU_NO_WIDE_STORE): 8-byte epilogue stores
     int nopair;          // experiment (AAU_RESW_NOPAIR): no two-taps-per-K-block packing of a short last chunk
 };

@@ -102,7 +102,14 @@ __device__ __forceinline__ void epi_pair_store(const C3Args& a, const aau_conv_d
 // NWV = 12 waves per workgroup (one workgroup per CU), PR = 16 patch rows.  (Two independent 6-wave workgroups per CU on
 // 8-row patches measured 20-30 % slower -- twice the barriers, 10 halo rows per 8 -- and an epilogue staggered between the
 // two halves of the waves 0-10 % slower: profiles/NOTES.md.)
-template <int CIN, int G, int NWV, int PR, int ABL, bool BNRED>
+// BNIN (aau_conv_igemm_bnin): the source tensor is the raw output z of the previous ConvBNReLU layer and
+// y = relu(z * scale + shift) is applied IN LDS: every lane transforms exactly the 16-byte pieces its own LDS-DMA
+// instructions fetched (it knows their addresses, and its own counted vmcnt says they have landed: no extra barrier),
+// one block ahead of the block the MFMAs read -- at the end of a step, behind the epilogue, when the accumulators are
+// dead.  Pieces outside the image stay the zeros the range check delivered (the padding of y is zero, not relu(shift)).
+// The arithmetic is aau_bn_act's (fp32 fma, max, round to the 16-bit type), so the result equals the two-kernel path bit
+// for bit while the 2 x 201 MB round trip of y at level 1 (2 x 50 MB at level 2) is gone.
+template <int CIN, int G, int NWV, int PR, int ABL, bool BNRED, bool BNIN = false>
 __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, int nunits, int strips, int nseg, int segh) {
     constexpr int abl = ABL;                           // timing ablations (AAU_C3S_ABL; builds with -DAAU_C3S_ABLATE only)
     constexpr int PXB = CIN == 48 ? 96 : 224;          // bytes per pixel in LDS
@@ -124,7 +131,8 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
     static_assert(NF <= NB, "the fills of a block are issued between the K-blocks of one row quad");
     constexpr unsigned OOB = 0x80000000u;
     static_assert(R >= PR + 2 + PR * D, "ring too small");
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [R][ROWB] ring | 1 KiB scratch | [4][96] floats
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];   // [R][ROWB] ring | 1 KiB scratch | [4][96] floats | BNIN: [2][96] floats
+    static_assert(!(BNIN && BNRED), "one fused form at a time");
 
     const aau_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -187,6 +195,8 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
     };
     issue_unit_setup();
     int irb = 0;                               // ring row of the next block to issue
+    unsigned vq = 0;                           // BNIN: one bit per issued piece of this lane, oldest in bit 0: inside the image?
+    int vqn = 0;
     // one LDS-DMA instruction (1 KiB: a quarter / half of a ring row) of the block under the issue cursor
     auto issue_one = [&](int i) {
         const bool live = iu < nunits;
@@ -200,6 +210,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
         const unsigned soff = row_ok ? (unsigned)(((in_ * d.H + y) * d.W) * d.src_pitch * 2) : 0u;
         const unsigned v = (row_ok && !(abl & 2)) ? ivec : OOB;       // abl: timing ablations (AAU_C3S_ABL), never set in production
         if (!(abl & 32)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(dstp), 16, (int)v, (int)soff, 0, 0);
+        if constexpr (BNIN) { vq |= (real && v != OOB ? 1u : 0u) << vqn; ++vqn; }
     };
     auto issue_end = [&]() {
         irb += PR; if (irb >= R) irb -= R;
@@ -228,6 +239,37 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
         }
         __syncthreads();
     }
+    float* inp = par + 4 * 96;                 // BNIN: [2][96] floats scale | shift of the INPUT channels
+    if constexpr (BNIN) {
+        for (int i = tid; i < CIN; i += 64 * NWV) { inp[i] = a.in_scale[i]; inp[96 + i] = a.in_shift[i]; }
+        __syncthreads();
+    }
+    int trb = 0;                               // BNIN: ring row of the next block to transform (stream order)
+    // y = relu(z * scale + shift) on this lane's own pieces of the oldest untransformed block (they have landed: caller)
+    auto xform_block = [&]() {
+        if constexpr (BNIN) {
+            float sc[8], sh[8];
+            const int c8 = fpart * 8 < CIN ? fpart * 8 : 0;
+            *(f32x4*)(sc) = *(const f32x4*)(inp + c8); *(f32x4*)(sc + 4) = *(const f32x4*)(inp + c8 + 4);
+            *(f32x4*)(sh) = *(const f32x4*)(inp + 96 + c8); *(f32x4*)(sh + 4) = *(const f32x4*)(inp + 96 + c8 + 4);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int idx = i * FW + wave;
+                const int r = idx / IPR;
+                int rr = trb + r; if (rr >= R) rr -= R;
+                if ((vq >> i) & 1u) {
+                    u32x4* pz = (u32x4*)(dsm + rr * ROWB + sub * 1024 + lane * 16);
+                    float f[8];
+                    unpack8(*pz, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+                    *pz = pack8(f);
+                }
+            }
+            vq >>= NF; vqn -= NF;
+            trb += PR; if (trb >= R) trb -= R;
+        }
+    };
     const unsigned par_off = (unsigned)(R * ROWB + 1024 + (g * 16 + 4 * fk) * 4);
     const bool want_stats = a.stats != nullptr;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -239,6 +281,10 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
 
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_block();
+    if constexpr (BNIN) {                      // the first block of the stream: every later one is transformed one step ahead
+        wait_vm_s<NF * (D - 1)>();
+        xform_block();
+    }
 
     int crb = 0;                               // ring row of block t
     bool prev_patch = false;
@@ -279,6 +325,7 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
             if (!(abl & 16)) {
                 if (!prev_patch) wait_vm_s<NF * (D - 1)>();
                 else wait_vm_s<NF * (D - 1) + NST>();
+                if constexpr (BNIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's transformed pieces are written
                 __builtin_amdgcn_s_barrier();
             }
             // block t + D goes into rows nobody reads any more; on a patch step its NF instructions are issued between
@@ -333,6 +380,13 @@ __global__ __launch_bounds__(64 * NWV, 3) void conv3x3s_kernel(const C3Args a, i
                     epilogue(soff);
                 }
             }
+            if constexpr (BNIN) {
+                // the NEXT block of the stream: its fills are older than the NF * (D - 1) fills issued since and this step's
+                // stores, so the same counts as at the top of the next step say that they have landed
+                if (cb >= 0) wait_vm_s<NF * (D - 1) + NST>();
+                else wait_vm_s<NF * (D - 1)>();
+                xform_block();
+            }
             crb += PR; if (crb >= R) crb -= R;
         }
     }
@@ -386,7 +440,7 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
     if (nunits > 0x7fffffff) { set_error("conv3x3s: too many units"); return AAU_E_INVALID; }
     const int grid = nunits < 256 * per_cu ? (int)nunits : 256 * per_cu;
     const size_t ring = c48 ? (size_t)64 * 2048 : (size_t)36 * 4096;
-    const size_t lds = ring + 1024 + 4 * 96 * 4;
+    const size_t lds = ring + 1024 + 4 * 96 * 4 + 2 * 96 * 4;
     int abl = 0;
     if (const char* e = getenv("AAU_C3S_ABL")) abl = atoi(e);       // timing ablations: 1 no MFMA, 2 fills out of range, 4 no stores, 8 no epilogue, 16 no barrier / wait, 32 no fill instructions
     prof_tag(c48 ? (g3 ? "conv3x3s<48,48>" : "conv3x3s<48,96>") : (g3 ? "conv3x3s<96,48>" : "conv3x3s<96,96>"));
@@ -398,6 +452,13 @@ int conv3x3s_launch(C3Args& a, hipStream_t s) {
     if (a.bn_z) {          // fused BatchNorm-backward sums (aau_conv_igemm_bnred): the default form only, 48 input channels
         go(conv3x3s_kernel<48, 3, 12, 16, 0, true>, 768);      // 48 -> 48 (the 48 -> 96 form spills at 168 VGPRs)
         return check_launch("aau_conv_igemm_bnred(3x3 strips)");
+    }
+    if (a.in_scale) {      // BatchNorm + ReLU of the producing layer applied on the input in LDS (aau_conv_igemm_bnin)
+        if (c48 && g3) go(conv3x3s_kernel<48, 3, 12, 16, 0, false, true>, 768);
+        else if (c48) go(conv3x3s_kernel<48, 6, 12, 16, 0, false, true>, 768);
+        else if (g3) go(conv3x3s_kernel<96, 3, 12, 16, 0, false, true>, 768);
+        else go(conv3x3s_kernel<96, 6, 12, 16, 0, false, true>, 768);
+        return check_launch("aau_conv_igemm_bnin(3x3 strips)");
     }
     auto pick = [&](auto ablc) {
         constexpr int A = decltype(ablc)::value;
@@ -460,3 +521,39 @@ extern "C" int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src,
     return conv3x3s_launch(a, s);
 }
 
+
+// 1 when aau_conv_igemm_bnin serves this descriptor: a 3x3 conv that the strip kernel takes, one dense source plane
+extern "C" int aau_conv_bnin_ok(const aau_conv_desc* d) {
+    if (!d || getenv("AAU_NO_BNIN") || getenv("AAU_NO_C3S")) return 0;
+    return conv3x3_applicable(d) && (d->Cin == 48 || d->Cin == 96) && (d->Cout == 48 || d->Cout == 96) &&
+           d->Cpad == (d->Cin == 48 ? 64 : 96) && !d->accumulate && !d->relu && d->src_pitch % 8 == 0 && d->dst_pitch % 8 == 0 &&
+           d->src_split_c <= 0 && d->dst_split_c <= 0;
+}
+
+// dst = conv3x3(relu(src * in_scale + in_shift), w) (+ statistics of dst): aau_bn_act followed by aau_conv_igemm, bit for
+// bit, without the activation ever leaving the chip (pipeline:59-65: the ReLU(BatchNorm(.)) of the PRODUCING block fused
+// into the consuming convolution's operand path)
+extern "C" int aau_conv_igemm_bnin(const aau_conv_desc* d, const aau_bf16* src, const float* in_scale, const float* in_shift,
+                                   const aau_bf16* wpk, aau_bf16* dst, aau_stat* stats, int64_t stats_bytes, void* stream) {
+    AAU_REQUIRE(d && src && in_scale && in_shift && wpk && dst, "aau_conv_igemm_bnin: null pointer");
+    AAU_REQUIRE(aau_conv_bnin_ok(d) && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
+                "aau_conv_igemm_bnin: descriptor not served (aau_conv_bnin_ok) or misaligned operands");
+    if (stats) AAU_CHECK_STAT("aau_conv_igemm_bnin", stats, stats_bytes, d->Cout);
+    const int64_t M = (int64_t)d->N * d->H * d->W;
+    const int64_t src_bytes = ((M - 1) * d->src_pitch + d->Cin) * 2;
+    AAU_REQUIRE(src_bytes < 0x7fffffff && M * d->dst_pitch * 2 < 0x7fffffff, "aau_conv_igemm_bnin: tensors must stay below 2 GiB");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(0, 2.0 * M * (double)d->Cout * d->Cin * 9, s);
+    prof_tag(nullptr, 2.0 * ((double)M * d->Cin + (double)M * d->Cout + (double)d->Cout * 9 * d->Cin));
+    C3Args a;
+    a.d = *d;
+    a.src = src; a.wpk = wpk; a.dst = dst; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr; a.stats = (float*)stats;
+    a.rev = next_traversal();
+    a.nchunk = d->Cpad / 32;
+    a.src_bytes = (unsigned)src_bytes;
+    a.wpk_bytes = (unsigned)((int64_t)d->Cout * 9 * d->Cpad * 2);
+    a.tiles_x = d->W / 16; a.tiles_y = d->H / 16;
+    a.nowide = 0; a.nopair = 0;
+    a.in_scale = in_scale; a.in_shift = in_shift;
+    return conv3x3s_launch(a, s);
+}

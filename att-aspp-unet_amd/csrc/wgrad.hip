@@ -385,7 +385,7 @@ int wg_reduce_launch(int mode, WRedArgs& r, hipStream_t s) {
 // wgrad3x3.hip
 bool wgrad3x3_applicable(const aau_conv_desc* d);
 int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
-                    int64_t ws_bytes, int64_t* need, hipStream_t s);
+                    int64_t ws_bytes, int64_t* need, hipStream_t s, const float* in_scale = nullptr, const float* in_shift = nullptr);
 
 // wgrad3x3r.hip
 int wgrad3x3r_variant(const aau_conv_desc* d);
@@ -443,8 +443,10 @@ static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipS
 
 }  // namespace aau
 
+// in_scale / in_shift (aau_conv_wgrad_bnin): src is a raw conv output, the kernel applies relu(src * scale + shift) on it
 static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
-                          int64_t ws_bytes, int64_t* need, void* stream) {
+                          int64_t ws_bytes, int64_t* need, void* stream, const float* in_scale = nullptr,
+                          const float* in_shift = nullptr) {
     using namespace aau;
     AAU_REQUIRE(d, "aau_conv_wgrad: null descriptor");
     AAU_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0,
@@ -469,6 +471,9 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
         AAU_REQUIRE(d->src_split_c % 8 == 0 && d->src_split_c < d->Cin && d->src_split_off % 8 == 0 && d->src_split_off >= 0,
                     "aau_conv_wgrad: src_split_c / src_split_off must be multiples of 8 inside the channel range");
     }
+    if (in_scale)
+        AAU_REQUIRE(wgrad3x3_applicable(d) && !split && wgrad3x3r_variant(d) == 0,
+                    "aau_conv_wgrad_bnin: descriptor not served (aau_conv_wgrad_bnin_ok)");
     if (wgrad3x3_applicable(d)) {
         const int rv = split ? 0 : wgrad3x3r_variant(d);
         if (need) return rv ? wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream)
@@ -481,7 +486,7 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
             return wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream);
         }
         prof_tag("wgrad3x3<3,8>", 2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout) + 4.0 * d->Cout * 9.0 * d->Cin);
-        return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream);
+        return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream, in_scale, in_shift);
     }
     const bool q2 = d->Cout > 48, c2 = d->Cin > 48;
     if (need) {
@@ -507,4 +512,20 @@ extern "C" int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const
 extern "C" int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes) {
     AAU_REQUIRE(bytes, "aau_conv_wgrad_ws_bytes: null pointer");
     return wgrad_dispatch(d, nullptr, nullptr, nullptr, nullptr, 0, bytes, nullptr);
+}
+
+// 1 when aau_conv_wgrad_bnin serves this descriptor (the all-taps 3x3 kernel, one source plane)
+extern "C" int aau_conv_wgrad_bnin_ok(const aau_conv_desc* d) {
+    using namespace aau;
+    if (!d || getenv("AAU_NO_BNIN")) return 0;
+    return wgrad3x3_applicable(d) && d->src_split_c <= 0 && d->dst_split_c <= 0 && wgrad3x3r_variant(d) == 0 &&
+           d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->src_pitch % 8 == 0 && d->dst_pitch % 8 == 0;
+}
+
+// dw += weight gradient with x = relu(src * in_scale + in_shift) as the convolution's input: aau_bn_act followed by
+// aau_conv_wgrad, bit for bit, without the activation in memory (the counterpart of aau_conv_igemm_bnin)
+extern "C" int aau_conv_wgrad_bnin(const aau_conv_desc* d, const aau_bf16* src, const float* in_scale, const float* in_shift,
+                                   const aau_bf16* dz, float* dw, float* ws, int64_t ws_bytes, void* stream) {
+    AAU_REQUIRE(in_scale && in_shift, "aau_conv_wgrad_bnin: null pointer");
+    return wgrad_dispatch(d, src, dz, dw, ws, ws_bytes, nullptr, stream, in_scale, in_shift);
 }

@@ -42,6 +42,10 @@ struct W3Args {
     int tiles_x, tiles_y;        // W/16, H/8
     int rev;                     // 1: workgroups take the split ranges from the end (aau_traverse)
     int noremap;                 // experiment (AAU_W3_NOREMAP): the round-1 order, split fastest, no XCD remap
+    // aau_conv_wgrad_bnin: src is the RAW conv output z of the producing BatchNorm -> ReLU layer; the kernel applies
+    // x = relu(z * in_scale + in_shift) in LDS on the pieces each lane fetched itself (see conv3x3s.hip, BNIN)
+    const float* in_scale = nullptr;
+    const float* in_shift = nullptr;
 };
 
 // QT = 16-channel q tiles per workgroup (3: 48 channels, 6: 96 channels); PR = patch rows per K-step.
@@ -50,7 +54,7 @@ struct W3Args {
 // NG = 2 (with QT = 6): 8 waves, two groups of four that share the staged x halo; group g owns q tiles 3g..3g+2 of the
 // 96-channel dz tile.  Same accumulators per wave and waves per SIMD as <3, 8, 1> at two workgroups per CU, but the
 // halo is staged once per 96 output channels instead of once per 48: -29 % L2 -> LDS fill bytes per FLOP.
-template <int QT, int PR, int NG = 1>
+template <int QT, int PR, int NG = 1, bool BNIN = false>
 __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
     constexpr int BQ = QT * 16;
     constexpr int NW = 4 * NG;                            // waves
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
     constexpr int XB = NLX * NW * 1024;                    // staged bytes (rows >= XROWS are zero fill)
     constexpr unsigned OOB = 0x80000000u;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB) + (BNIN ? 2 * 48 * 4 : 0)];
+    float* const s_in = (float*)(smem + 2 * (YB + XB));        // BNIN: [2][48] scale | shift of this workgroup's channel tile
     auto sY = [&](int b) -> unsigned char* { return smem + b * (YB + XB); };
     auto sX = [&](int b) -> unsigned char* { return smem + b * (YB + XB) + YB; };
 
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
         if (d.src_split_c > 0 && xch[i] >= d.src_split_c) xch[i] += d.src_split_off - d.src_split_c;   // second plane (aau.h)
     }
 
+    unsigned xv = 0;        // BNIN: bit i = x piece i of the buffer staged last lies inside the image (this lane)
     auto stage = [&](int buf, int patch) {
         const int pxi = patch % a.tiles_x;
         const int t2 = patch / a.tiles_x;
@@ -146,8 +152,39 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
             const bool ok = (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
             const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + xch[i]) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX(buf) + (i * NW + wave) * 1024), 16, (int)v, 0, 0, 0);
+            if constexpr (BNIN) xv = i == 0 ? (ok ? 1u : 0u) : (xv | ((ok ? 1u : 0u) << i));
         }
     };
+    // BNIN: x = relu(z * scale + shift) on the pieces of buffer `buf` this lane fetched itself (its own vmcnt(0) says they
+    // have landed; the barrier behind it publishes them).  Pieces outside the image stay the zeros the range check
+    // delivered: the padding of the activation is zero, not relu(shift).  aau_bn_act's arithmetic, bit for bit.
+    auto xform = [&](int buf) {
+        if constexpr (BNIN) {
+#pragma unroll
+            for (int i = 0; i < NLX; ++i) {
+                if ((xv >> i) & 1u) {
+                    const int p = (i * NW + wave) * 64 + lane;
+                    const int s8 = (p % 6) * 8;
+                    u32x4* pz = (u32x4*)(sX(buf) + (i * NW + wave) * 1024 + lane * 16);
+                    float f[8], sc[8], sh[8];
+                    *(f32x4*)(sc) = *(const f32x4*)(s_in + s8); *(f32x4*)(sc + 4) = *(const f32x4*)(s_in + s8 + 4);
+                    *(f32x4*)(sh) = *(const f32x4*)(s_in + 48 + s8); *(f32x4*)(sh + 4) = *(const f32x4*)(s_in + 48 + s8 + 4);
+                    unpack8(*pz, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+                    *pz = pack8(f);
+                }
+            }
+        }
+    };
+    if constexpr (BNIN) {
+        for (int i = tid; i < 48; i += 256 * NG) {
+            const bool in = c0 + i < d.Cin;
+            s_in[i] = in ? a.in_scale[c0 + i] : 0.f;
+            s_in[48 + i] = in ? a.in_shift[c0 + i] : 0.f;
+        }
+        // (published by the barrier behind the first stage below)
+    }
 
     // ---- this wave's column tiles: ct = 7*wave + n, n = 0..6 (tap = ct/3, channel group j = ct%3) ----
     f32x4 acc[QW][7];
@@ -235,6 +272,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
     int patch = p_begin;
     stage(0, patch);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (BNIN) { __syncthreads(); xform(0); }      // (s_in is visible behind the first barrier)
     __syncthreads();
     int buf = 0;
     while (true) {
@@ -243,6 +281,7 @@ __global__ __launch_bounds__(256 * NG) void wgrad3x3_kernel(const W3Args a) {
         compute(buf);
         if (!more) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform(buf ^ 1);
         __syncthreads();
         buf ^= 1;
         ++patch;
@@ -280,7 +319,7 @@ bool wgrad3x3_applicable(const aau_conv_desc* d) {
            d->W == d->Wo && d->H % 8 == 0 && d->W % 16 == 0;
 }
 
-template <int QT, int PR, int NG = 1>
+template <int QT, int PR, int NG = 1, bool BNIN = false>
 static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
     constexpr int BQ = QT * 16;
     a.tiles_x = d->W / 16;
@@ -310,7 +349,7 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_by
     a.ws = ws;
     a.rev = next_traversal();
     a.noremap = getenv("AAU_W3_NOREMAP") ? 1 : 0;
-    hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR, NG>), dim3((unsigned)grid), dim3(256 * NG), 0, s, a);
+    hipLaunchKernelGGL((wgrad3x3_kernel<QT, PR, NG, BNIN>), dim3((unsigned)grid), dim3(256 * NG), 0, s, a);
     if (!ws) return check_launch("aau_conv_wgrad(3x3)");
     WRedArgs r;
     r.ws = ws; r.dw = a.dw;
@@ -321,10 +360,11 @@ static int launch_w3(W3Args& a, const aau_conv_desc* d, float* ws, int64_t ws_by
 }
 
 int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
-                    int64_t ws_bytes, int64_t* need, hipStream_t s) {
+                    int64_t ws_bytes, int64_t* need, hipStream_t s, const float* in_scale, const float* in_shift) {
     W3Args a;
     a.d = *d;
     a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
+    a.in_scale = in_scale; a.in_shift = in_shift;
     const int64_t npix = (int64_t)d->N * d->H * d->W;
     const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin + (d->src_split_c > 0 ? d->src_split_off - d->src_split_c : 0)) * 2;
     const int64_t zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
@@ -336,6 +376,7 @@ int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16*
     if (d->Cout > 48 && getenv("AAU_W3_WIDE")) return launch_w3<6, 4>(a, d, ws, ws_bytes, need, s);
     if (getenv("AAU_W3_PR4")) return launch_w3<3, 4>(a, d, ws, ws_bytes, need, s);   // experiment: 4 workgroups per CU
     if (d->Cout > 48 && getenv("AAU_W3_NG2")) return launch_w3<6, 8, 2>(a, d, ws, ws_bytes, need, s);   // experiment
+    if (in_scale) return launch_w3<3, 8, 1, true>(a, d, ws, ws_bytes, need, s);
     return launch_w3<3, 8>(a, d, ws, ws_bytes, need, s);
 }
 

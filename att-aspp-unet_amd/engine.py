@@ -85,9 +85,14 @@ class _Rec:
         self.ops.append((f, tuple(conv), name, 1 if side else 0, self.label))
         self.uses_side |= side
 
-    def add_wgrad(self, desc, src, dz, dw, side=False):
-        """aau_conv_wgrad with the shared split-K workspace, which is sized and patched in by ``bind_wgrad_ws``."""
-        self.add("aau_conv_wgrad", desc, src, dz, dw, None, 0, side=side)
+    def add_wgrad(self, desc, src, dz, dw, side=False, src_bn=None):
+        """aau_conv_wgrad with the shared split-K workspace, which is sized and patched in by ``bind_wgrad_ws``.
+        ``src_bn`` = (scale, shift): ``src`` is the raw conv output of the producing layer and its BatchNorm + ReLU is applied
+        on the operand inside the kernel (aau_conv_wgrad_bnin)."""
+        if src_bn is None:
+            self.add("aau_conv_wgrad", desc, src, dz, dw, None, 0, side=side)
+        else:
+            self.add("aau_conv_wgrad_bnin", desc, src, src_bn[0], src_bn[1], dz, dw, None, 0, side=side)
         self.wg_ops.append((len(self.ops) - 1, ops.conv_wgrad_ws_bytes(desc)))
 
     def bind_wgrad_ws(self, device):
@@ -99,7 +104,7 @@ class _Rec:
         self.keep.append(ws)
         for i, _ in self.wg_ops:
             f, a, name, sid, lab = self.ops[i]
-            self.ops[i] = (f, a[:4] + (ws.data_ptr(), nbytes), name, sid, lab)
+            self.ops[i] = (f, a[:-2] + (ws.data_ptr(), nbytes), name, sid, lab)      # (..., ws, ws_bytes) end both forms
 
     def callback(self, fn: Callable[[], None]):
         self.ops.append((None, fn, "callback", 0, ""))
@@ -396,6 +401,18 @@ class Plan:
                 return False
         return True
 
+    def _bnin_ok(self, cname, N, H, W, Cprev) -> bool:
+        """May conv ``cname`` take the previous ConvBNReLU's RAW output (Cprev channels, dense) with that layer's BatchNorm +
+        ReLU applied on the operand -- in the forward conv AND in the weight gradient (both must be served)?"""
+        if not self.train or self.eng.no_bnin:
+            return False
+        cv = self.eng.store.convs[cname]
+        if cv.kind != "conv" or cv.k != 3 or cv.dil != 1 or cv.I != Cprev:
+            return False
+        fwd = ops.conv_desc(N, H, W, cv.I, cv.I, H, W, cv.O, cv.O, 3, 3, 1, 1, 1, cv.cpad_f)
+        wg = ops.conv_desc(N, H, W, cv.I, cv.I, H, W, cv.O, cv.O, 3, 3, 1, 1, 1)
+        return ops.conv_bnin_ok(fwd) and ops.conv_wgrad_bnin_ok(wg)
+
     def new(self, *shape, dtype=None):
         dtype = self.eng.adt if dtype is None else dtype
         return torch.zeros(*shape, dtype=dtype, device=self.dev)
@@ -414,10 +431,13 @@ class Plan:
 
     # ---- ConvBNReLU on MFMA: forward ----
     def cbr_fwd(self, cname, bname, src, sp, N, H, W, ydst, yp, drop=False, bcast_hw=0, pool=None, head=None,
-                src_split=(0, 0), group=None):
+                src_split=(0, 0), group=None, src_bn=None, skip_act=False):
         """conv(cname) -> BN(bname) -> ReLU; returns the per-layer record used by the backward.
         ``head`` (training only): the out_conv ConvP when this is the last ConvBNReLU -- its activation feeds out_conv
-        alone, so BN + ReLU + out_conv run as one pass and neither the activation nor its gradient is stored."""
+        alone, so BN + ReLU + out_conv run as one pass and neither the activation nor its gradient is stored.
+        ``skip_act`` / ``src_bn`` (training only): a ConvBNReLU whose ONLY consumer is the next 3x3 conv does not write its
+        activation (skip_act); that conv reads the raw output ``src`` = z and applies relu(z * scale + shift), src_bn =
+        (scale, shift), on the operand in LDS -- forward and weight gradient (aau_conv_igemm_bnin / aau_conv_wgrad_bnin)."""
         st = self.eng.store
         cv, bn = st.convs[cname], st.bns[bname]
         self.fwd.label = _short(cname)
@@ -425,7 +445,7 @@ class Plan:
         pad = cv.dil * (cv.k // 2)
         w = self.bnbuf(bn.C)
         rec = dict(cv=cv, bn=bn, w=w, N=N, H=H, W=W, M=M, src=src, sp=sp, drop=drop, bcast_hw=bcast_hw,
-                   src_split=src_split)
+                   src_split=src_split, src_bn=src_bn)
         if self.train:
             z = self.new(M, cv.O)
             d = ops.conv_desc(N, H, W, cv.I, sp, H, W, cv.O, cv.O, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_f,
@@ -445,10 +465,15 @@ class Plan:
                 group["post"].append(post)
                 rec["z"] = z
                 return rec
-            self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
+            if src_bn is not None:
+                self.fwd.add("aau_conv_igemm_bnin", d, src, src_bn[0], src_bn[1], cv.pk_f, z, w["stats"])
+            else:
+                self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
             self._bn_finalize(bn, w, M)
             Mo = M * bcast_hw if bcast_hw else M
-            if head is not None:
+            if skip_act:
+                assert head is None and pool is None and not bcast_hw and not drop
+            elif head is not None:
                 self.fwd.add("aau_bn_act_outconv", z, cv.O, w["scale"], w["shift"], head.w, head.bias, self.logits, M, cv.O)
                 rec["head"] = head
             elif pool is not None:
@@ -535,7 +560,7 @@ class Plan:
         if defer_wgrad is not None:
             defer_wgrad.append((dwd, r["src"], dz, cv.dw, b.label))     # emitted later as one grouped launch
         else:
-            b.add_wgrad(dwd, r["src"], dz, cv.dw, side=ov)
+            b.add_wgrad(dwd, r["src"], dz, cv.dw, side=ov, src_bn=r.get("src_bn"))
         if din is not None:
             dd = ops.conv_desc(N, H, W, cv.O, cv.O, H, W, cv.I, dinp, cv.k, cv.k, 1, pad, cv.dil, cv.cpad_d,
                                accumulate=accumulate, dst_split=din_split)
@@ -598,7 +623,9 @@ class Plan:
         cv0, bn0 = st.convs["d1.0.block.0"], st.bns["d1.0.block.1"]
         f.label = "d1.0"
         w0 = self.bnbuf(c)
-        y10 = self.new(Ms[0], c)
+        # training: d1.1 reads the raw first-layer output and applies its BatchNorm + ReLU on the operand (no y10 at all)
+        bnin10 = eng.no_recompute_z1 and self._bnin_ok("d1.1.block.0", B, H, W, c)
+        y10 = None if bnin10 else self.new(Ms[0], c)
         r10 = dict(cv=cv0, bn=bn0, w=w0, N=B, H=H, W=W, M=Ms[0], src=self.x, sp=1, drop=False, bcast_hw=0)
         if eng.no_recompute_z1:
             z10 = self.new(Ms[0], c)
@@ -607,7 +634,8 @@ class Plan:
                 self._bn_finalize(bn0, w0, Ms[0])
             else:
                 self._bn_fold(bn0, w0)
-            f.add("aau_bn_act", z10, c, y10, c, w0["scale"], w0["shift"], Ms[0], c, 1, 0, 0.0, self.drop_seed)
+            if not bnin10:
+                f.add("aau_bn_act", z10, c, y10, c, w0["scale"], w0["shift"], Ms[0], c, 1, 0, 0.0, self.drop_seed)
         else:
             # z of the first layer (9 FMAs per value) is never stored: statistics pass, then y straight from the frame;
             # the backward recomputes it the same way (aau_conv1_bn_bwd_reduce, aau_bn_bwd_apply_conv1)
@@ -619,15 +647,21 @@ class Plan:
                 self._bn_fold(bn0, w0)
             f.add("aau_conv1_bn_act", self.x, cv0.w, y10, c, w0["scale"], w0["shift"], B, H, W, c)
         r10["z"] = z10
-        r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, skips[0], skip_p[0], pool=pools[0])
+        if bnin10:
+            r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", z10, c, B, H, W, skips[0], skip_p[0], pool=pools[0],
+                               src_bn=(w0["scale"], w0["shift"]))
+        else:
+            r11 = self.cbr_fwd("d1.1.block.0", "d1.1.block.1", y10, c, B, H, W, skips[0], skip_p[0], pool=pools[0])
         enc.append((r10, r11))
         for lv in range(1, 4):
             h, w_ = Hs[lv], Ws[lv]
-            ya = self.new(Ms[lv], Cs[lv])
+            bnin = self._bnin_ok(f"d{lv + 1}.1.block.0", B, h, w_, Cs[lv])
+            ya = None if bnin else self.new(Ms[lv], Cs[lv])
             ra = self.cbr_fwd(f"d{lv + 1}.0.block.0", f"d{lv + 1}.0.block.1", pools[lv - 1], Cs[lv - 1], B, h, w_,
-                              ya, Cs[lv])
-            rb = self.cbr_fwd(f"d{lv + 1}.1.block.0", f"d{lv + 1}.1.block.1", ya, Cs[lv], B, h, w_, skips[lv],
-                              skip_p[lv], pool=pools[lv])
+                              ya, Cs[lv], skip_act=bnin)
+            rb = self.cbr_fwd(f"d{lv + 1}.1.block.0", f"d{lv + 1}.1.block.1", ra["z"] if bnin else ya, Cs[lv], B, h, w_,
+                              skips[lv], skip_p[lv], pool=pools[lv],
+                              src_bn=(ra["w"]["scale"], ra["w"]["shift"]) if bnin else None)
             enc.append((ra, rb))
 
         # ---------------- bridge: ASPP (pipeline:67-83) or ConvBNReLU + Dropout (ablation:194-197) ----------------
@@ -750,13 +784,15 @@ class Plan:
                 gate = dict(kind="bn", wg=wg, wx=wx, psi=psi, bg=bg, bx=bx, b1=b1, wgb=wgb, wxb=wxb, w1=w1, zg=zg, zx=zx,
                             psi_pre=psi_pre, alpha=alpha, Fi=Fi,
                             wrep=self.red_arena.take(STAT_REPLICAS * Fi) if tr else None)
-            ya = self.new(Mo, Co)
+            bnin = self._bnin_ok(f"{name}.conv.1.block.0", B, ho, wo, Co)
+            ya = None if bnin else self.new(Mo, Co)
             ra = self.cbr_fwd(f"{name}.conv.0.block.0", f"{name}.conv.0.block.1", cat, cat_p[lv], B, ho, wo, ya, Co,
-                              src_split=cat_split[lv])
+                              src_split=cat_split[lv], skip_act=bnin)
             fuse_head = tr and lv == 0 and not eng.no_fuse_head
             yb = None if fuse_head else self.new(Mo, Co)
-            rb = self.cbr_fwd(f"{name}.conv.1.block.0", f"{name}.conv.1.block.1", ya, Co, B, ho, wo, yb, Co,
-                              head=st.convs["out_conv"] if fuse_head else None)
+            rb = self.cbr_fwd(f"{name}.conv.1.block.0", f"{name}.conv.1.block.1", ra["z"] if bnin else ya, Co, B, ho, wo,
+                              yb, Co, head=st.convs["out_conv"] if fuse_head else None,
+                              src_bn=(ra["w"]["scale"], ra["w"]["shift"]) if bnin else None)
             dec.append(dict(lv=lv, name=name, up=up, cat=cat, gate=gate, ra=ra, rb=rb, g_in=g_in, g_c=g_c, Co=Co,
                             hi=hi, wi=wi, ho=ho, wo=wo, Mo=Mo, out=yb))
             g_in, g_c = yb, Co
@@ -1011,6 +1047,7 @@ class Engine:
         self.no_fuse_head = os.environ.get("AAU_NO_FUSE_HEAD", "0") == "1"
         self.no_wgrad_group = os.environ.get("AAU_NO_WGRAD_GROUP", "0") == "1"
         self.no_fuse_bnred = os.environ.get("AAU_NO_BNRED", "0") == "1"
+        self.no_bnin = os.environ.get("AAU_NO_BNIN", "0") == "1"     # A/B: ConvBNReLU pairs with the activation in memory
         # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
         # reading the routed gradient the reduce pass stored
         self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"

@@ -220,6 +220,30 @@ def conv_igemm_bnred(desc: ConvDesc, src, wpk, dst, z, zp, scale, shift, smean, 
                                      _p(sinvstd), _p(sums), _nb(sums), _stream()), "aau_conv_igemm_bnred")
 
 
+def conv_bnin_ok(desc: ConvDesc) -> bool:
+    return bool(fn("aau_conv_bnin_ok")(C.byref(desc)))
+
+
+def conv_igemm_bnin(desc: ConvDesc, src, in_scale, in_shift, wpk, dst, stats=None):
+    """dst = conv(relu(src * in_scale + in_shift)): the producing layer's BatchNorm + ReLU applied on the operand in LDS
+    (include/aau.h: bit for bit aau_bn_act followed by aau_conv_igemm)."""
+    if stats is not None:
+        _check_stats(stats, desc.Cout, "conv_igemm_bnin")
+    check(fn("aau_conv_igemm_bnin")(C.byref(desc), _p(src), _p(in_scale), _p(in_shift), _p(wpk), _p(dst), _p(stats),
+                                    _nb(stats) if stats is not None else 0, _stream()), "aau_conv_igemm_bnin")
+
+
+def conv_wgrad_bnin_ok(desc: ConvDesc) -> bool:
+    return bool(fn("aau_conv_wgrad_bnin_ok")(C.byref(desc)))
+
+
+def conv_wgrad_bnin(desc: ConvDesc, src, in_scale, in_shift, dz, dw, ws=None):
+    """dw += weight gradient with relu(src * in_scale + in_shift) as the input (include/aau.h)."""
+    nb = 0 if ws is None else ws.numel() * ws.element_size()
+    check(fn("aau_conv_wgrad_bnin")(C.byref(desc), _p(src), _p(in_scale), _p(in_shift), _p(dz), _p(dw), _p(ws), nb, _stream()),
+          "aau_conv_wgrad_bnin")
+
+
 def stats_to_red(stats, Cc, red):
     _check_stats(stats, Cc, "stats_to_red")
     check(fn("aau_stats_to_red")(_p(stats), _nb(stats), Cc, _p(red), _stream()), "aau_stats_to_red")

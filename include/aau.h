@@ -127,6 +127,21 @@ int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src, const aau_
                          void* stream);
 int aau_stats_to_red(const aau_stat* stats, int64_t stats_bytes, int C, float* red, void* stream);
 
+/* ConvBNReLU -> ConvBNReLU without the activation in between (pipeline:59-65 twice, e.g. d1 = Sequential(ConvBNReLU,  */
+/* ConvBNReLU), pipeline:113): src is the RAW conv output z of the producing layer and in_scale / in_shift its folded   */
+/* BatchNorm affine (aau_bn_finalize); the kernel applies y = relu(z * in_scale + in_shift) in LDS behind the landing     */
+/* fill, so dst (+ stats) equals aau_bn_act followed by aau_conv_igemm BIT FOR BIT while y is never written or read.      */
+/* Served for the descriptors aau_conv_bnin_ok() accepts (3x3, 48 / 96 channels in and out: the strip kernel).            */
+int aau_conv_bnin_ok(const aau_conv_desc* d);
+int aau_conv_igemm_bnin(const aau_conv_desc* d, const aau_bf16* src, const float* in_scale, const float* in_shift,
+                        const aau_bf16* wpk, aau_bf16* dst, aau_stat* stats, int64_t stats_bytes, void* stream);
+/* ... and the same for the weight gradient of that convolution: x = relu(src * in_scale + in_shift) applied in LDS, */
+/* dw += as aau_conv_wgrad (workspace: aau_conv_wgrad_ws_bytes of the same descriptor).  aau_conv_wgrad_bnin_ok():       */
+/* descriptors that take the all-taps 3x3 kernel.                                                                       */
+int aau_conv_wgrad_bnin_ok(const aau_conv_desc* d);
+int aau_conv_wgrad_bnin(const aau_conv_desc* d, const aau_bf16* src, const float* in_scale, const float* in_shift,
+                        const aau_bf16* dz, float* dw, float* ws, int64_t ws_bytes, void* stream);
+
 /* 1 when the launch this descriptor selects supports its two-plane operands (src_split_c /  */
 /* dst_split_c): mode 0 = aau_conv_igemm (the resident-weight 3x3 kernels), 1 = aau_conv_wgrad */
 /* (wgrad3x3).  A descriptor with split operands that the selected kernel cannot serve fails   */

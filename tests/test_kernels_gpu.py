@@ -678,6 +678,80 @@ def test_strip_kernel_forward_stats_and_eval_epilogue(ops, case):
     assert torch.equal(out, out3) and torch.equal(stats, st3)
 
 
+@pytest.mark.parametrize("case", STRIP_CASES)
+def test_strip_kernel_with_batchnorm_relu_applied_on_the_input(ops, case):
+    """aau_conv_igemm_bnin: the producing layer's y = relu(z * scale + shift) is applied on the operand in LDS.  Same bits
+    -- output and statistics -- as aau_bn_act into a buffer followed by aau_conv_igemm (pipeline:59-65 twice), including
+    the zero padding at the image border (the padding of y is 0, not relu(shift)) and channels with negative scale; and
+    against the fp32 reference of conv(relu(bn(z)))."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(1000 + sum(case))
+    z = R.bf16_round(torch.randn(N, H, W, Cin, generator=g) * 1.5)
+    w = R.bf16_round(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    scale = torch.randn(Cin, generator=g)                        # both signs
+    shift = torch.randn(Cin, generator=g) * 0.5 + 0.4            # mostly positive: relu(shift) != 0 would show in the border
+    M = N * H * W
+    cpad = ops.cpad_of(Cin)
+    zd, wd = dev(z.to(torch.bfloat16)), dev(pack_fwd(w, cpad))
+    d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 1, 1, cpad)
+    assert ops.conv_bnin_ok(d)
+    # the two-kernel path
+    y = torch.empty(M, Cin, dtype=torch.bfloat16, device="cuda")
+    ops.bn_act(zd, Cin, y, Cin, dev(scale), dev(shift), M, Cin)
+    ref = torch.empty(M, Cout, dtype=torch.bfloat16, device="cuda")
+    st_ref = ops.stats_buffer(Cout)
+    ops.conv_igemm(d, y, wd, ref, stats=st_ref)
+    # the fused path (NaN-poisoned destination)
+    out = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    st = ops.stats_buffer(Cout)
+    with launch_tags() as lt:
+        ops.conv_igemm_bnin(d, zd, dev(scale), dev(shift), wd, out, stats=st)
+    assert [t.split(" ")[0] for t in lt] == [f"conv3x3s<{Cin},{Cout}>"], lt
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    # the statistics: per-wave fp32 partial sums of the SAME accumulator values, added exactly across waves and workgroups;
+    # the two instantiations of the kernel may contract v * v + s differently, so the totals agree to fp32 rounding of the
+    # partial sums, not to the last bit (which replica a workgroup adds into also follows the alternating traversal)
+    ta, tb = ops.stats_totals(st, Cout), ops.stats_totals(st_ref, Cout)
+    assert float((ta - tb).abs().max()) <= 1e-5 * float(tb.abs().max())
+    assert torch.equal(zd.cpu(), z.to(torch.bfloat16))           # the source is not written
+    yr = R.bf16_round(torch.relu(z * scale + shift))
+    assert rel_err(out.float().cpu().view(N, H, W, Cout), R.conv_fwd(yr, w)) < 6e-3
+    # without statistics, and repeated: same bits
+    out2 = torch.empty_like(out)
+    ops.conv_igemm_bnin(d, zd, dev(scale), dev(shift), wd, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("case", [(2, 32, 48, 48, 48), (1, 64, 16, 48, 48), (3, 16, 80, 48, 48)])
+def test_weight_gradient_with_batchnorm_relu_applied_on_the_input(ops, case):
+    """aau_conv_wgrad_bnin: same bits as aau_bn_act into a buffer followed by aau_conv_wgrad (deterministic split-K
+    workspace), zero padding of the ACTIVATION at the border included."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(2000 + sum(case))
+    z = R.bf16_round(torch.randn(N, H, W, Cin, generator=g) * 1.5)
+    dz = R.bf16_round(torch.randn(N, H, W, Cout, generator=g))
+    scale = torch.randn(Cin, generator=g)
+    shift = torch.randn(Cin, generator=g) * 0.5 + 0.4
+    M = N * H * W
+    zd, dzd = dev(z.to(torch.bfloat16)), dev(dz.to(torch.bfloat16))
+    d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, 3, 3, 1, 1, 1)
+    assert ops.conv_wgrad_bnin_ok(d)
+    ws = torch.empty(ops.conv_wgrad_ws_bytes(d) // 4, device="cuda")
+    y = torch.empty(M, Cin, dtype=torch.bfloat16, device="cuda")
+    ops.bn_act(zd, Cin, y, Cin, dev(scale), dev(shift), M, Cin)
+    ref = torch.zeros(Cout, 9, Cin, device="cuda")
+    ops.conv_wgrad(d, y, dzd, ref, ws)
+    got = torch.zeros(Cout, 9, Cin, device="cuda")
+    ops.conv_wgrad_bnin(d, zd, dev(scale), dev(shift), dzd, got, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    yr = R.bf16_round(torch.relu(z * scale + shift))
+    want = R.conv_wgrad(yr, dz, (Cout, Cin, 3, 3), 1)
+    assert rel_err(got.cpu().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), want) < 2e-3
+
+
 def test_strip_kernel_data_gradient_matches_conv2d_input(ops):
     N, H, W, Cin, Cout = 2, 64, 48, 96, 48          # forward 96 -> 48; its data gradient is a 48 -> 96 convolution
     g = torch.Generator().manual_seed(11)

@@ -294,13 +294,14 @@ def test_experiment_switches_do_not_change_the_result(A, switch, monkeypatch):
         assert float(cos) > 0.9999 and abs(float(ga.norm() / gb.norm()) - 1) < 1e-3
 
 
-@pytest.mark.parametrize("switch", ["AAU_NO_BNRED", "AAU_NO_IGEMM_MULTI", "AAU_NO_POOLBRANCH", "AAU_BRIDGE_WG_SIDE"])
+@pytest.mark.parametrize("switch", ["AAU_NO_BNRED", "AAU_NO_IGEMM_MULTI", "AAU_NO_POOLBRANCH", "AAU_BRIDGE_WG_SIDE", "AAU_NO_BNIN"])
 def test_default_on_fused_paths_against_their_off_switches_at_the_metric_shape(A, switch, monkeypatch):
     """Whole-step A/B of the fused paths that are ON by default, at the shape where they engage (base_c 48, 8 x 512 x 512:
     48-channel strip levels -> aau_conv_igemm_bnred; bridge 384 -> 768 on 8192 pixels = 256 wide tiles per branch ->
     aau_conv_igemm_multi; batch <= 16 -> poolbranch kernels).  The multi-problem launch and the side-stream placement of
     the grouped weight gradient run the same arithmetic (bitwise); the fused BatchNorm-backward sums and the image-pool
-    branch kernels add in another order."""
+    branch kernels add in another order; the BatchNorm + ReLU applied on a conv's operand (aau_conv_igemm_bnin /
+    aau_conv_wgrad_bnin) gives the same conv outputs bit for bit, its statistics' fp32 partial sums may round differently."""
     from att_aspp_unet_amd import synth
     args = Namespace(stage="main", edge_w=0.05, neg_bce_w=0.05)
     x, y = synth.make_frames(8, 512, seed=5)
@@ -320,9 +321,11 @@ def test_default_on_fused_paths_against_their_off_switches_at_the_metric_shape(A
 
     la, ga, na = run()
     assert "aau_conv_igemm_bnred" in na and "aau_conv_igemm_multi" in na and "aau_poolbranch_fwd" in na
+    assert na.count("aau_conv_igemm_bnin") == 2 and na.count("aau_conv_wgrad_bnin") == 2      # d1.1 and u1.conv.1
     monkeypatch.setenv(switch, "1")
     lb, gb, nb = run()
-    off = {"AAU_NO_BNRED": "aau_conv_igemm_bnred", "AAU_NO_POOLBRANCH": "aau_poolbranch_fwd"}.get(switch)
+    off = {"AAU_NO_BNRED": "aau_conv_igemm_bnred", "AAU_NO_POOLBRANCH": "aau_poolbranch_fwd",
+           "AAU_NO_BNIN": "aau_conv_igemm_bnin"}.get(switch)
     if off:
         assert off not in nb
     if switch == "AAU_NO_IGEMM_MULTI":
