@@ -235,6 +235,55 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
     // are workgroup wide), a trip past p_end stages zeros
     const int ntrip = (p_end - p_begin + KG - 1) / KG;
     int patch = p_begin + grp, k = 0;
+    if constexpr (KG == 2) {
+        // PING-PONG (round 4): the two groups run half a trip apart.  Between the two barriers of a trip group 0 multiplies
+        // (transposed reads + 108 MFMAs per wave) while group 1 issues the LDS-DMA of its next patch and waits for the
+        // current one; behind the second barrier they swap.  In lockstep (round 3) both groups issued their DMAs, then both
+        // multiplied: the matrix pipes idled through every issue phase (the wgradL kernel measured 1.5x between the two
+        // forms).  A group's buffer b is restaged only after the barrier that ends its multiply half; waits are counted
+        // (all but the youngest NLY + NLX = 9 DMAs of this wave have landed), trips past the range stage zeros.
+        static_assert(NLY + NLX == 9, "the counted waits below");
+        if (grp == 0) {
+            stage(0, patch);
+            stage(1, patch + KG);
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            while (true) {
+                __builtin_amdgcn_s_barrier();
+                compute(0);
+                __builtin_amdgcn_s_barrier();
+                stage(0, patch + 2 * KG);
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                patch += KG;
+                if (++k == ntrip) break;
+                __builtin_amdgcn_s_barrier();
+                compute(1);
+                __builtin_amdgcn_s_barrier();
+                stage(1, patch + 2 * KG);
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                patch += KG;
+                if (++k == ntrip) break;
+            }
+        } else {
+            stage(0, patch);
+            while (true) {
+                __builtin_amdgcn_s_barrier();
+                stage(1, patch + KG);
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                compute(0);
+                patch += KG;
+                if (++k == ntrip) break;
+                __builtin_amdgcn_s_barrier();
+                stage(0, patch + KG);
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                compute(1);
+                patch += KG;
+                if (++k == ntrip) break;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero stages past the range: the combine reuses the buffers
+    } else {
     stage(0, patch);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -253,6 +302,7 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         patch += KG; ++k;
+    }
     }
     if constexpr (KG == 2) {
         if (a.ws) {     // group 1 hands its 27 accumulator tiles to group 0 through LDS (the staging buffers are dead)
