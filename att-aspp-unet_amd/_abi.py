@@ -61,6 +61,10 @@ _SIGS = {
     "aau_conv_bnred_ok": [C.POINTER(ConvDesc)],
     "aau_conv_igemm_bnred": [C.POINTER(ConvDesc), P, P, P, P, I, P, P, P, P, P, L, P],
     "aau_stats_to_red": [P, L, I, P, P],
+    "aau_bn_finalize_multi": [I, P, L, I, L, F, F, P],
+    "aau_bn_act_multi": [I, P, I, I, L, I, I, P],
+    "aau_bn_bwd_reduce_multi": [I, P, I, I, I, I, I, I, I, P],
+    "aau_bn_bwd_apply_multi": [I, P, I, I, I, L, I, I, P],
     "aau_conv_bnin_ok": [C.POINTER(ConvDesc)],
     "aau_conv_wgrad_bnin_ok": [C.POINTER(ConvDesc)],
     "aau_conv_wgrad_bnin": [C.POINTER(ConvDesc), P, P, P, P, P, P, L, P],

@@ -48,10 +48,10 @@ __device__ __forceinline__ void ldf8(const float* p, float f[8]) {
 // 256 threads = 8 channels x 32 replica lanes: a lane loads its replica's two (hi, lo) pairs with 16-B loads, the 32
 // lanes are added with shuffles (integers: exact, any order), lane 0 forms mean / variance in fp64 and rounds once.
 // (One thread per channel walking the 32 replicas took 10-15 us per launch, 31 launches per step.)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const long long* stats, const float* gamma, const float* beta,
-                                                          float* rmean, float* rvar, int64_t* nbt, float* scale,
-                                                          float* shift, float* smean, float* sinvstd, int C, float count,
-                                                          float eps, float mom) {
+__device__ __forceinline__ void bn_finalize_body(const long long* stats, const float* gamma, const float* beta,
+                                                  float* rmean, float* rvar, int64_t* nbt, float* scale,
+                                                  float* shift, float* smean, float* sinvstd, int C, float count,
+                                                  float eps, float mom) {
     static_assert(AAU_STAT_REPLICAS == 32, "one replica per lane of a 32-lane group");
     typedef __attribute__((ext_vector_type(2))) long long i64x2;
     const int r = threadIdx.x & 31;
@@ -92,6 +92,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const long long* stats
     }
 }
 
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const long long* stats, const float* gamma, const float* beta,
+                                                          float* rmean, float* rvar, int64_t* nbt, float* scale,
+                                                          float* shift, float* smean, float* sinvstd, int C, float count,
+                                                          float eps, float mom) {
+    bn_finalize_body(stats, gamma, beta, rmean, rvar, nbt, scale, shift, smean, sinvstd, C, count, eps, mom);
+}
+// Several BatchNorm layers of the same width in ONE launch (blockIdx.y = layer): the four spatial branches of the ASPP
+// (pipeline:80-83), the two 1x1 convs of an attention gate.  Each layer's arithmetic is exactly the single launch's.
+constexpr int BN_MULTI_MAX = 8;
+struct BnMulti { const void* p[BN_MULTI_MAX][12]; };
+__global__ __launch_bounds__(256) void bn_finalize_multi_kernel(const BnMulti a, int C, float count, float eps, float mom) {
+    const void* const* q = a.p[blockIdx.y];
+    bn_finalize_body((const long long*)q[0], (const float*)q[1], (const float*)q[2], (float*)q[3], (float*)q[4], (int64_t*)q[5],
+                     (float*)q[6], (float*)q[7], (float*)q[8], (float*)q[9], C, count, eps, mom);
+}
+
 __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rmean,
                                     const float* rvar, float* scale, float* shift, int C, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,10 +119,10 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
 
 // y = relu?(z*scale+shift) (* dropout).  A thread owns one 8-channel group (scale / shift live in 16
 // registers) and walks over pixels; consecutive threads cover consecutive 16-B vectors of a pixel row.
-__global__ __launch_bounds__(256) void bn_act_kernel(const unsigned short* z, int zp, unsigned short* y, int yp,
-                                                     const float* scale, const float* shift, int64_t M, int C,
-                                                     int relu, int64_t bhw, float drop_p, const uint64_t* seedp,
-                                                     int64_t ppb) {
+__device__ __forceinline__ void bn_act_body(const unsigned short* z, int zp, unsigned short* y, int yp,
+                                            const float* scale, const float* shift, int64_t M, int C,
+                                            int relu, int64_t bhw, float drop_p, const uint64_t* seedp,
+                                            int64_t ppb) {
     const CGMap mp(C);
     const int tid = threadIdx.x;
     if (tid >= mp.T) return;
@@ -130,6 +146,18 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const unsigned short* z, in
         }
         st16(y + m * yp + c, pack8(f));
     }
+}
+
+__global__ __launch_bounds__(256) void bn_act_kernel(const unsigned short* z, int zp, unsigned short* y, int yp,
+                                                     const float* scale, const float* shift, int64_t M, int C,
+                                                     int relu, int64_t bhw, float drop_p, const uint64_t* seedp,
+                                                     int64_t ppb) {
+    bn_act_body(z, zp, y, yp, scale, shift, M, C, relu, bhw, drop_p, seedp, ppb);
+}
+__global__ __launch_bounds__(256) void bn_act_multi_kernel(const BnMulti a, int zp, int yp, int64_t M, int C, int relu, int64_t ppb) {
+    const void* const* q = a.p[blockIdx.y];
+    bn_act_body((const unsigned short*)q[0], zp, (unsigned short*)q[1], yp, (const float*)q[2], (const float*)q[3], M, C, relu, 0,
+                0.f, nullptr, ppb);
 }
 
 __global__ __launch_bounds__(256) void maxpool2_kernel(const unsigned short* y, int yp, unsigned short* p, int pp,
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const unsigned short* 
 // ---- backward pass 1: masked gradient + per-channel sums ----
 // POOL = true: one thread per 2x2 window (H, W even) so the max-pool routing needs no re-reads.
 template <bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+__device__ __forceinline__ void bn_bwd_reduce_body(
     const unsigned short* z, int zp, const unsigned short* dy, int dyp, const unsigned short* dpool, int dpp,
     unsigned short* dz, int dzp, const float* scale, const float* shift, const float* mean, const float* invstd,
     float* red, int N, int H, int W, int C, int relu, float drop_p, const uint64_t* seedp, int64_t items_per_block,
@@ -292,16 +320,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const unsigned short* z, int zp, const unsigned short* dy, int dyp, const unsigned short* dpool, int dpp,
+    unsigned short* dz, int dzp, const float* scale, const float* shift, const float* mean, const float* invstd,
+    float* red, int N, int H, int W, int C, int relu, float drop_p, const uint64_t* seedp, int64_t items_per_block,
+    float* ws) {
+    bn_bwd_reduce_body<POOL>(z, zp, dy, dyp, dpool, dpp, dz, dzp, scale, shift, mean, invstd, red, N, H, W, C, relu, drop_p, seedp,
+                             items_per_block, ws);
+}
+// [z, dy, scale, shift, mean, invstd, red, ws] per layer
+__global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(const BnMulti a, int zp, int dyp, int N, int H, int W, int C,
+                                                                  int relu, int64_t items_per_block) {
+    const void* const* q = a.p[blockIdx.y];
+    bn_bwd_reduce_body<false>((const unsigned short*)q[0], zp, (const unsigned short*)q[1], dyp, nullptr, 0, nullptr, 0,
+                              (const float*)q[2], (const float*)q[3], (const float*)q[4], (const float*)q[5], (float*)q[6], N, H, W,
+                              C, relu, 0.f, nullptr, items_per_block, (float*)q[7]);
+}
+
 // ---- backward pass 2: dz = gamma*invstd*(g - mean(g) - zhat*mean(g*zhat)) in place ----
 // dy == null: the masked gradient g is read from dz (written by the reduce pass, pooled layers);
 // dy != null: g = relu'(z*scale+shift) * dropout(dy) is recomputed here, saving one tensor write + read.
 // A thread owns one channel group: its seven per-channel constants live in registers.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* z, int zp, unsigned short* dz, int dzp,
-                                                           const float* gamma, const float* mean, const float* invstd,
-                                                           const float* red, float* dgamma, float* dbeta, int64_t M,
-                                                           int C, const unsigned short* dy, int dyp, const float* scale,
-                                                           const float* shift, int relu, float drop_p, const uint64_t* seedp,
-                                                           const float* dl, const float* wout, int64_t ppb) {
+__device__ __forceinline__ void bn_bwd_apply_body(const unsigned short* z, int zp, unsigned short* dz, int dzp,
+                                                  const float* gamma, const float* mean, const float* invstd,
+                                                  const float* red, float* dgamma, float* dbeta, int64_t M,
+                                                  int C, const unsigned short* dy, int dyp, const float* scale,
+                                                  const float* shift, int relu, float drop_p, const uint64_t* seedp,
+                                                  const float* dl, const float* wout, int64_t ppb) {
     const uint64_t seed = drop_p > 0.f ? *seedp : 0;
     extern __shared__ float sm[];   // [2][C] replica sums, computed once per workgroup
     for (int cc = threadIdx.x; cc < C; cc += 256) {
@@ -363,6 +409,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
         }
         st16(dz + m * dzp + c, pack8(g));
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* z, int zp, unsigned short* dz, int dzp,
+                                                           const float* gamma, const float* mean, const float* invstd,
+                                                           const float* red, float* dgamma, float* dbeta, int64_t M,
+                                                           int C, const unsigned short* dy, int dyp, const float* scale,
+                                                           const float* shift, int relu, float drop_p, const uint64_t* seedp,
+                                                           const float* dl, const float* wout, int64_t ppb) {
+    bn_bwd_apply_body(z, zp, dz, dzp, gamma, mean, invstd, red, dgamma, dbeta, M, C, dy, dyp, scale, shift, relu, drop_p, seedp, dl,
+                      wout, ppb);
+}
+// [z, dz, gamma, mean, invstd, red, dgamma, dbeta, dy, scale, shift] per layer
+__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(const BnMulti a, int zp, int dzp, int dyp, int64_t M, int C, int relu,
+                                                                 int64_t ppb) {
+    const void* const* q = a.p[blockIdx.y];
+    bn_bwd_apply_body((const unsigned short*)q[0], zp, (unsigned short*)q[1], dzp, (const float*)q[2], (const float*)q[3],
+                      (const float*)q[4], (const float*)q[5], (float*)q[6], (float*)q[7], M, C, (const unsigned short*)q[8], dyp,
+                      (const float*)q[9], (const float*)q[10], relu, 0.f, nullptr, nullptr, nullptr, ppb);
 }
 
 // The apply pass of a POOLED layer (the encoder's second ConvBNReLU: its output feeds the skip connection and, through
@@ -600,8 +664,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_conv1_kernel(const unsigned 
 // ---- fixed-order sum of the workgroup rows (common.h: red_fold_launch) ----
 // A workgroup owns 4 consecutive 16-B vectors of the row (64 B) and 64 row lanes: thread (rl, v) adds rows rl, rl+64, ..
 // in that order, the 64 partial sums are then added in lane order.
-__global__ __launch_bounds__(256) void red_fold_kernel(const float* ws, int n, int nblk, float* out, int n_out, float* acc,
-                                                       int n_acc, float* acc2) {
+__device__ __forceinline__ void red_fold_body(const float* ws, int n, int nblk, float* out, int n_out, float* acc,
+                                              int n_acc, float* acc2) {
     __shared__ f32x4 sm[256];
     const int v = (int)blockIdx.x * 4 + (threadIdx.x & 3), rl = threadIdx.x >> 2;
     const int nv = n >> 2;
@@ -629,6 +693,16 @@ __global__ __launch_bounds__(256) void red_fold_kernel(const float* ws, int n, i
     } else if (i == n_out + n_acc && acc2) {
         acc2[0] += a[0];
     }
+}
+
+__global__ __launch_bounds__(256) void red_fold_kernel(const float* ws, int n, int nblk, float* out, int n_out, float* acc,
+                                                       int n_acc, float* acc2) {
+    red_fold_body(ws, n, nblk, out, n_out, acc, n_acc, acc2);
+}
+// [ws, out] per layer (the reduce pass's entries 7 and 6)
+__global__ __launch_bounds__(256) void red_fold_multi_kernel(const BnMulti a, int n, int nblk) {
+    const void* const* q = a.p[blockIdx.y];
+    red_fold_body((const float*)q[7], n, nblk, (float*)q[6], n, nullptr, 0, nullptr);
 }
 
 int red_fold_launch(const float* ws, int n, int nblk, float* out, int n_out, float* acc, int n_acc, float* acc2, hipStream_t s) {
@@ -868,4 +942,81 @@ extern "C" int aau_bn_bwd_apply_conv1(const aau_bf16* z, int z_pitch, const floa
                            dy_pitch, scale, shift, x, H, W, ws, w, ppb_signed);
     red_fold_launch(ws, C * 9, (int)blocks, nullptr, 0, dw, C * 9, nullptr, (hipStream_t)stream);
     return check_launch("aau_bn_bwd_apply_conv1");
+}
+
+// ---- several same-width BatchNorm layers per launch (aau.h: *_multi) ----
+static int bn_multi_table(const char* fn, const void* const* tab, int n, int per, BnMulti& out) {
+    AAU_REQUIRE(tab && n >= 1 && n <= BN_MULTI_MAX && per <= 12, "%s: %d layers (1..%d)", fn, n, BN_MULTI_MAX);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < per; ++k) out.p[i][k] = tab[i * per + k];
+    return AAU_OK;
+}
+
+extern "C" int aau_bn_finalize_multi(int n, const void* const* tab, int64_t stats_bytes, int C, int64_t count, float eps, float momentum,
+                                     void* stream) {
+    BnMulti a;
+    if (int rc = bn_multi_table("aau_bn_finalize_multi", tab, n, 10, a)) return rc;
+    AAU_REQUIRE(C > 0 && count > 0, "aau_bn_finalize_multi: C=%d count=%lld", C, (long long)count);
+    for (int i = 0; i < n; ++i) {
+        AAU_REQUIRE(a.p[i][0] && a.p[i][1] && a.p[i][2] && a.p[i][6] && a.p[i][7] && a.p[i][8] && a.p[i][9], "aau_bn_finalize_multi: null pointer in layer %d", i);
+        AAU_CHECK_STAT("aau_bn_finalize_multi", a.p[i][0], stats_bytes, C);
+    }
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3((C + 7) / 8, n), dim3(256), 0, (hipStream_t)stream, a, C, (float)count, eps, momentum);
+    return check_launch("aau_bn_finalize_multi");
+}
+
+extern "C" int aau_bn_act_multi(int n, const void* const* tab, int z_pitch, int y_pitch, int64_t M, int C, int relu, void* stream) {
+    BnMulti a;
+    if (int rc = bn_multi_table("aau_bn_act_multi", tab, n, 4, a)) return rc;
+    CHK_C("aau_bn_act_multi", C);
+    AAU_REQUIRE(M > 0 && z_pitch % 8 == 0 && y_pitch % 8 == 0, "aau_bn_act_multi: bad args");
+    for (int i = 0; i < n; ++i) AAU_REQUIRE(a.p[i][0] && a.p[i][1] && a.p[i][2] && a.p[i][3], "aau_bn_act_multi: null pointer in layer %d", i);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    int64_t blocks, ppb;
+    rows_split(M, CGMap(C).PL, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
+    hipLaunchKernelGGL(bn_act_multi_kernel, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)stream, a, z_pitch, y_pitch, M, C, relu, ppb);
+    return check_launch("aau_bn_act_multi");
+}
+
+extern "C" int aau_bn_bwd_reduce_multi(int n, const void* const* tab, int z_pitch, int dy_pitch, int N, int H, int W, int C, int relu,
+                                       void* stream) {
+    BnMulti a;
+    if (int rc = bn_multi_table("aau_bn_bwd_reduce_multi", tab, n, 8, a)) return rc;
+    CHK_C("aau_bn_bwd_reduce_multi", C);
+    AAU_REQUIRE(N > 0 && H > 0 && W > 0 && z_pitch % 8 == 0 && dy_pitch % 8 == 0, "aau_bn_bwd_reduce_multi: bad args");
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 8; ++k) AAU_REQUIRE(a.p[i][k], "aau_bn_bwd_reduce_multi: null pointer in layer %d", i);
+    const CGMap mp(C);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    const int64_t items = (int64_t)N * H * W;
+    int64_t blocks = (items + mp.PL * 8 - 1) / (mp.PL * 8);
+    const int64_t cap = 1024 / n > 64 ? 1024 / n : 64;      // the same number of workgroups as ONE single-layer launch
+    if (blocks > cap) blocks = cap;
+    int64_t ipb = (items + blocks - 1) / blocks;
+    blocks = (items + ipb - 1) / ipb;
+    if (next_traversal()) ipb = -ipb;
+    hipLaunchKernelGGL(bn_bwd_reduce_multi_kernel, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)stream, a, z_pitch, dy_pitch, N, H,
+                       W, C, relu, ipb);
+    hipLaunchKernelGGL(red_fold_multi_kernel, dim3((unsigned)((2 * C / 4 + 3) / 4), n), dim3(256), 0, (hipStream_t)stream, a, 2 * C,
+                       (int)blocks);
+    return check_launch("aau_bn_bwd_reduce_multi");
+}
+
+extern "C" int aau_bn_bwd_apply_multi(int n, const void* const* tab, int z_pitch, int dz_pitch, int dy_pitch, int64_t M, int C, int relu,
+                                      void* stream) {
+    BnMulti a;
+    if (int rc = bn_multi_table("aau_bn_bwd_apply_multi", tab, n, 11, a)) return rc;
+    CHK_C("aau_bn_bwd_apply_multi", C);
+    AAU_REQUIRE(M > 0 && z_pitch % 8 == 0 && dz_pitch % 8 == 0 && dy_pitch % 8 == 0, "aau_bn_bwd_apply_multi: bad args");
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 11; ++k) AAU_REQUIRE(a.p[i][k] || k == 6 || k == 7, "aau_bn_bwd_apply_multi: null pointer in layer %d", i);
+    ProfScope prof(2, 0, (hipStream_t)stream);
+    int64_t blocks, ppb;
+    rows_split(M, CGMap(C).PL, &blocks, &ppb);
+    if (next_traversal()) ppb = -ppb;
+    hipLaunchKernelGGL(bn_bwd_apply_multi_kernel, dim3((unsigned)blocks, n), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, a, z_pitch,
+                       dz_pitch, dy_pitch, M, C, relu, ppb);
+    return check_launch("aau_bn_bwd_apply_multi");
 }

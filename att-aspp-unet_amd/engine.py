@@ -463,6 +463,7 @@ class Plan:
                                  self.drop_p if drop else 0.0, self.drop_seed)
                 assert head is None and pool is None and not bcast_hw
                 group["post"].append(post)
+                group.setdefault("bn", []).append((bn, w, z, ydst, yp, drop))
                 rec["z"] = z
                 return rec
             if src_bn is not None:
@@ -500,7 +501,7 @@ class Plan:
 
     # ---- ConvBNReLU backward: dy (+ pooled gradient) -> dW, dgamma, dbeta, d(input) ----
     def cbr_bwd(self, r, dy, dyp, dpool=None, dpp=0, din=None, dinp=0, accumulate=0, din_stats=None,
-                defer_wgrad=None, din_split=(0, 0), defer_dgrad=None, red_next=None):
+                defer_wgrad=None, din_split=(0, 0), defer_dgrad=None, red_next=None, dz_given=None):
         """``red_next``: the record of the ConvBNReLU layer whose output gradient is ``din`` (its only source): where the
         library can (aau_conv_bnred_ok), the data-gradient conv below also accumulates THAT layer's BatchNorm-backward
         sums in its epilogue and the layer's own reduce pass over (z, dy) is not recorded."""
@@ -510,9 +511,11 @@ class Plan:
         b.label = _short(cv.name)
         dp_ = self.drop_p if r["drop"] else 0.0
         fuse1 = cv.kind == "first" and dpool is None and dp_ == 0.0 and not self.eng.no_fuse_conv1
-        dz = None if fuse1 else self.new(M, cv.O)
+        dz = dz_given if dz_given is not None else (None if fuse1 else self.new(M, cv.O))
         head = r.get("head")
-        if head is not None:
+        if dz_given is not None:
+            pass        # the BatchNorm backward of this layer ran in a multi-layer launch (bridge branches)
+        elif head is not None:
             # network head: dy = dlogits x w_out is rank one and never stored (see cbr_fwd)
             b.add("aau_bn_bwd_reduce_outconv", r["z"], cv.O, self.dlogits, head.w, w["scale"], w["shift"], w["mean"],
                   w["invstd"], w["red"], head.dw, head.dbias, self.red_ws, M, cv.O)
@@ -676,14 +679,14 @@ class Plan:
             cat5 = self.new(M5, ncat)
             # training: the spatial branches' convolutions as ONE multi-problem launch where the library serves it (each
             # of them is one workgroup per CU on its own), longest problem first
-            grp = dict(convs=[], post=[]) if tr and 2 <= nbr <= 4 and not eng.no_igemm_multi else None
+            grp = dict(convs=[], post=[]) if tr and 2 <= nbr <= 8 else None
             br = [self.cbr_fwd(f"bridge.blocks.{i}.0", f"bridge.blocks.{i}.1", p4, Cs[3], B, h5, w5,
                                cat5[:, i * Cb:], ncat, group=grp) for i in range(nbr)]
             if grp is not None:
                 cvs = grp["convs"]
                 order = sorted(range(len(cvs)), key=lambda i: -(cvs[i][0].KH * cvs[i][0].KW) * 100 + cvs[i][0].dil)
                 descs = [cvs[i][0] for i in order]
-                if ops.conv_igemm_multi_ok(descs):
+                if not eng.no_igemm_multi and len(descs) <= 4 and ops.conv_igemm_multi_ok(descs):
                     f.label = "bridge(multi)"
                     pack = ops.igemm_multi_args(descs, [cvs[i][1] for i in order], [cvs[i][2] for i in order],
                                                 [cvs[i][3] for i in order], [cvs[i][4] for i in order])
@@ -694,8 +697,22 @@ class Plan:
                     for d_, src_, pk_, z_, st_, lab in cvs:
                         f.label = lab
                         f.add("aau_conv_igemm", d_, src_, pk_, z_, None, None, None, st_)
-                for post in grp["post"]:
-                    post()
+                bns = grp.get("bn", [])
+                if (not eng.no_bn_multi and 2 <= len(bns) <= 8 and len({b_[0].C for b_ in bns}) == 1
+                        and len({b_[4] for b_ in bns}) == 1 and not any(b_[5] for b_ in bns)):
+                    # the branches' BatchNorm statistics and activations: one launch each for all of them
+                    f.label = "bridge(multi)"
+                    Cn = bns[0][0].C
+                    tabF = ops.ptr_table([[w_["stats"], bn_.gamma, bn_.beta, bn_.rm, bn_.rv, bn_.nbt, w_["scale"], w_["shift"],
+                                           w_["mean"], w_["invstd"]] for bn_, w_, _, _, _, _ in bns])
+                    tabA = ops.ptr_table([[z_, y_, w_["scale"], w_["shift"]] for _, w_, z_, y_, _, _ in bns])
+                    f.keep.extend([tabF, tabA] + [t for bn_, w_, z_, y_, _, _ in bns for t in (bn_.rm, bn_.rv, bn_.nbt, z_, y_)])
+                    f.add("aau_bn_finalize_multi", len(bns), tabF, ops.stat_words(Cn) * 8, Cn, M5, 1e-5, 0.1)
+                    f.add("aau_bn_act_multi", len(bns), tabA, Cn, bns[0][4], M5, Cn, 1)
+                    self.bn_multi_fwd = True
+                else:
+                    for post in grp["post"]:
+                        post()
             pooled = self.new(B, Cs[3])
             gap_ws = self.new(ops.GAP_WS_ROWS, B, max(Cs[3], Cb), dtype=F32)     # one row per pixel slab
             f.label = "bridge.pool"
@@ -908,9 +925,24 @@ class Plan:
             # launch as well (aau_conv_igemm_group): the sum stays in registers across the branches
             dg = []
             self.cbr_bwd(rproj, dy, Cb, din=dcat5, dinp=ncat, defer_wgrad=wg)
+            dzs = [None] * nbr
+            if getattr(self, "bn_multi_fwd", False):
+                # the branches' BatchNorm backward as one reduce (+ fold) and one apply launch for all of them
+                b.label = "bridge(multi)"
+                dzs = [self.new(M5, Cb) for _ in range(nbr)]
+                rws = self.new(nbr, 2 * Cb * 1024, dtype=F32)
+                dys = [dcat5[:, i * Cb:] for i in range(nbr)]
+                tabR = ops.ptr_table([[r["z"], dys[i], r["w"]["scale"], r["w"]["shift"], r["w"]["mean"], r["w"]["invstd"],
+                                       r["w"]["red"], rws[i]] for i, r in enumerate(br)])
+                tabP = ops.ptr_table([[r["z"], dzs[i], r["bn"].gamma, r["w"]["mean"], r["w"]["invstd"], r["w"]["red"],
+                                       r["bn"].dgamma, r["bn"].dbeta, dys[i], r["w"]["scale"], r["w"]["shift"]]
+                                      for i, r in enumerate(br)])
+                b.keep.extend([tabR, tabP, rws] + dys)
+                b.add("aau_bn_bwd_reduce_multi", nbr, tabR, Cb, ncat, B, h5, w5, Cb, 1)
+                b.add("aau_bn_bwd_apply_multi", nbr, tabP, Cb, Cb, ncat, M5, Cb, 1)
             for i, r in enumerate(br):
                 self.cbr_bwd(r, dcat5[:, i * Cb:], ncat, din=dp4, dinp=Cs[3], accumulate=1 if i > 0 else 0, defer_wgrad=wg,
-                             defer_dgrad=dg)
+                             defer_dgrad=dg, dz_given=dzs[i])
             # The grouped weight gradient is latency-bound (one or two workgroups per CU, each waiting ~2 us for its next
             # K-step: scripts/probes/wl_sched.py) and nothing needs its result before the gradient bucket closes.  Opt-in
             # (AAU_BRIDGE_WG_SIDE=1): on the side stream beside the grouped data gradient and the image-pool branch --
@@ -1048,6 +1080,7 @@ class Engine:
         self.no_wgrad_group = os.environ.get("AAU_NO_WGRAD_GROUP", "0") == "1"
         self.no_fuse_bnred = os.environ.get("AAU_NO_BNRED", "0") == "1"
         self.no_bnin = os.environ.get("AAU_NO_BNIN", "0") == "1"     # A/B: ConvBNReLU pairs with the activation in memory
+        self.no_bn_multi = os.environ.get("AAU_NO_BN_MULTI", "0") == "1"   # A/B: one BatchNorm launch per ASPP branch
         # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
         # reading the routed gradient the reduce pass stored
         self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"

@@ -141,6 +141,13 @@ def conv_wgrad_group_ok(descs, lone_ok: bool = False) -> bool:
     return bool(fn("aau_conv_wgrad_group_ok")((ConvDesc * n)(*descs), n))
 
 
+def ptr_table(rows):
+    """Host array of device pointers for the *_multi entry points (include/aau.h): rows of tensors (None -> NULL), row
+    major.  Keep the returned object -- and the tensors -- alive while launches that use it may run."""
+    flat = [0 if t is None else t.data_ptr() for row in rows for t in row]
+    return (C.c_void_p * len(flat))(*flat)
+
+
 def wgrad_group_queue_words() -> int:
     """int32 words of the work-queue heads of aau_conv_wgrad_group (the caller zeroes them before every call)."""
     return int(fn("aau_conv_wgrad_group_queue_bytes")()) // 4

@@ -251,6 +251,23 @@ int aau_bn_finalize(const aau_stat* stats, int64_t stats_bytes, const float* gam
 int aau_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float* scale, float* shift, int C, float eps,
                      void* stream);
+
+/* Several BatchNorm layers of the SAME width in one launch each (blockIdx.y = layer; n <= 8): the four spatial branches  */
+/* of the ASPP (pipeline:80-83) run their statistics / activation / backward passes as 2 + 3 launches instead of 8 + 12.   */
+/* `tab` is a HOST array of n rows of pointers, in the order of the single-layer call's pointer arguments:                 */
+/*   finalize_multi   [stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd]     */
+/*   act_multi        [z, y, scale, shift]                         (ReLU optional, no dropout / broadcast)                 */
+/*   bwd_reduce_multi [z, dy, scale, shift, mean, invstd, red, ws] (ws: 2 C x 1024 floats of scratch per layer)            */
+/*   bwd_apply_multi  [z, dz, gamma, mean, invstd, red, dgamma, dbeta, dy, scale, shift]                                   */
+/* Every layer's arithmetic and order of additions are those of aau_bn_finalize / aau_bn_act / aau_bn_bwd_reduce /          */
+/* aau_bn_bwd_apply with the same grid: bitwise the same results as n single launches whose reduce grid is capped alike.  */
+int aau_bn_finalize_multi(int n, const void* const* tab, int64_t stats_bytes, int C, int64_t count, float eps,
+                          float momentum, void* stream);
+int aau_bn_act_multi(int n, const void* const* tab, int z_pitch, int y_pitch, int64_t M, int C, int relu, void* stream);
+int aau_bn_bwd_reduce_multi(int n, const void* const* tab, int z_pitch, int dy_pitch, int N, int H, int W, int C, int relu,
+                            void* stream);
+int aau_bn_bwd_apply_multi(int n, const void* const* tab, int z_pitch, int dz_pitch, int dy_pitch, int64_t M, int C,
+                           int relu, void* stream);
 /* Dropout masks are counter based: keep(m, c) = hash(*drop_seed, m*C + c) >= p.  drop_seed is */
 /* a DEVICE pointer (read only when drop_p > 0, may be NULL otherwise): the caller advances it  */
 /* on the stream once per step, so a step captured as a hipGraph draws a new mask per replay.  */

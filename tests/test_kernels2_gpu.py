@@ -571,3 +571,75 @@ def test_bn_backward_sums_are_order_independent_and_exact(ops, case):
     assert not torch.isnan(outs[1]).any()
     err = (outs[0].double().cpu() - ref).abs().max() / ref.abs().max()
     assert float(err) < 2e-5, float(err)
+
+
+def test_multi_layer_batchnorm_launches_equal_the_single_layer_ones(ops):
+    """aau_bn_finalize_multi / aau_bn_act_multi / aau_bn_bwd_reduce_multi / aau_bn_bwd_apply_multi (the ASPP branches,
+    pipeline:80-83): each layer of a multi launch gives the bits of its single-layer launch -- statistics, running statistics,
+    activations (written into channel slices of one concat buffer), dz, dgamma / dbeta; the backward sums agree to fp32
+    rounding (the multi launch splits the pixels over fewer workgroups per layer)."""
+    from att_aspp_unet_amd._abi import fn, check
+    n, N, H, W, Cc = 3, 2, 16, 24, 64
+    M = N * H * W
+    g = torch.Generator().manual_seed(4)
+    zs = [dev((torch.randn(M, Cc, generator=g) * (1 + i)).to(torch.bfloat16)) for i in range(n)]
+    gam = [dev(torch.rand(Cc, generator=g) + 0.5) for _ in range(n)]
+    bet = [dev(torch.randn(Cc, generator=g) * 0.3) for _ in range(n)]
+    dcat = dev(torch.randn(M, n * Cc + 16, generator=g).to(torch.bfloat16))       # the gradients: slices of one wider buffer
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def stats_of(z):
+        st = ops.stats_buffer(Cc)
+        d = ops.conv_desc(N, H, W, Cc, Cc, H, W, Cc, Cc, Cpad=ops.cpad_of(Cc))
+        # identity 1x1 conv: its epilogue accumulates (sum, sum of squares) of z
+        wid = torch.zeros(Cc, 1, ops.cpad_of(Cc), dtype=torch.bfloat16)
+        wid[torch.arange(Cc), 0, torch.arange(Cc)] = 1
+        out = torch.empty(M, Cc, dtype=torch.bfloat16, device="cuda")
+        ops.conv_igemm(d, z, dev(wid), out, stats=st)
+        return st
+
+    def run(multi):
+        f32 = lambda *s: torch.zeros(*s, device="cuda")
+        sts = [stats_of(z) for z in zs]
+        sc, sh, mu, isd = ([f32(Cc) for _ in range(n)] for _ in range(4))
+        rm, rv = [f32(Cc) + 0.1 for _ in range(n)], [f32(Cc) + 1.0 for _ in range(n)]
+        nbt = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(n)]
+        cat = torch.zeros(M, n * Cc + 16, dtype=torch.bfloat16, device="cuda")
+        ys = [cat[:, i * Cc:] for i in range(n)]
+        dys = [dcat[:, i * Cc:] for i in range(n)]
+        red = [f32(2 * Cc) for _ in range(n)]
+        dzs = [torch.zeros(M, Cc, dtype=torch.bfloat16, device="cuda") for _ in range(n)]
+        dgam, dbet = [f32(Cc) + 1 for _ in range(n)], [f32(Cc) + 2 for _ in range(n)]
+        if multi:
+            tabF = ops.ptr_table([[sts[i], gam[i], bet[i], rm[i], rv[i], nbt[i], sc[i], sh[i], mu[i], isd[i]] for i in range(n)])
+            check(fn("aau_bn_finalize_multi")(n, tabF, ops.stat_words(Cc) * 8, Cc, M, 1e-5, 0.1, stream))
+            tabA = ops.ptr_table([[zs[i], ys[i], sc[i], sh[i]] for i in range(n)])
+            check(fn("aau_bn_act_multi")(n, tabA, Cc, n * Cc + 16, M, Cc, 1, stream))
+            ws = f32(n, 2 * Cc * 1024)
+            tabR = ops.ptr_table([[zs[i], dys[i], sc[i], sh[i], mu[i], isd[i], red[i], ws[i]] for i in range(n)])
+            check(fn("aau_bn_bwd_reduce_multi")(n, tabR, Cc, n * Cc + 16, N, H, W, Cc, 1, stream))
+            tabP = ops.ptr_table([[zs[i], dzs[i], gam[i], mu[i], isd[i], red[i], dgam[i], dbet[i], dys[i], sc[i], sh[i]]
+                                  for i in range(n)])
+            check(fn("aau_bn_bwd_apply_multi")(n, tabP, Cc, Cc, n * Cc + 16, M, Cc, 1, stream))
+        else:
+            for i in range(n):
+                ops.bn_finalize(sts[i], gam[i], bet[i], rm[i], rv[i], nbt[i], sc[i], sh[i], mu[i], isd[i], Cc, M)
+                ops.bn_act(zs[i], Cc, ys[i], n * Cc + 16, sc[i], sh[i], M, Cc)
+                ops.bn_bwd_reduce(zs[i], Cc, dys[i], n * Cc + 16, None, 0, None, Cc, sc[i], sh[i], mu[i], isd[i], red[i], N, H, W, Cc)
+                ops.bn_bwd_apply(zs[i], Cc, dzs[i], Cc, gam[i], mu[i], isd[i], red[i], dgam[i], dbet[i], M, Cc, dys[i],
+                                 n * Cc + 16, sc[i], sh[i])
+        torch.cuda.synchronize()
+        return dict(sc=sc, sh=sh, mu=mu, isd=isd, rm=rm, rv=rv, nbt=nbt, cat=cat, red=red, dz=dzs, dgam=dgam, dbet=dbet)
+
+    a, b = run(False), run(True)
+    for k in ("sc", "sh", "mu", "isd", "rm", "rv", "nbt"):
+        for i in range(n):
+            assert torch.equal(a[k][i], b[k][i]), (k, i)
+    assert torch.equal(a["cat"], b["cat"]) and float(b["cat"][:, n * Cc:].abs().max()) == 0
+    for i in range(n):
+        assert float((a["red"][i] - b["red"][i]).abs().max()) <= 1e-5 * float(a["red"][i].abs().max())
+        assert rel_err(b["dz"][i], a["dz"][i]) < 1e-2
+        assert float((a["dgam"][i] - b["dgam"][i]).abs().max()) <= 1e-5 * float(a["dgam"][i].abs().max()) + 1e-6
+        assert float((a["dbet"][i] - b["dbet"][i]).abs().max()) <= 1e-5 * float(a["dbet"][i].abs().max()) + 1e-6
+    # with the single-layer sums handed to the multi apply the gradients are the same bits
+    assert int(b["nbt"][0]) == 1
