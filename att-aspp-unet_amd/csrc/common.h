@@ -173,6 +173,28 @@ __device__ __forceinline__ void swap_pair8(const float a[4], const float b[4], f
     }
 }
 
+// 16-byte buffer store with the row part of the address in the SCALAR offset.  gfx950 reads the four data registers of a
+// buffer_store_dwordx4 AFTER the instruction has issued: a vector instruction that rewrites them in the next cycle reaches
+// the store (seen here: dword 0 of lanes 12-15 of every row of 16 carried the NEXT accumulator pair's raw fp32 bits).
+// hipcc pads that hazard itself only when the scalar offset is NOT a register (LLVM GCNHazardRecognizer::
+// createsVALUHazard: "this hazard only exists if the instruction is not using a register in the soffset field"), so with
+// the builtin + register soffset the emitted code had a v_mov into the data register directly behind the store -- wrong
+// outputs whenever instruction fetch lets the two issue back to back (it came and went with code placement; round 3 took
+// it for a miscounted vmcnt).  The store is therefore issued from an asm statement that carries its own wait states.
+// (An asm store is not in hipcc's vmcnt bookkeeping: every wait that depends on these stores is hand-counted, NST below.)
+__device__ __forceinline__ void store_b128_soff(u32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+// 16-byte buffer load with a scalar offset, issued from asm so that hipcc does not count it: beside LDS-DMA builtins the
+// compiler waits vmcnt(0) for every ordinary load (guide 5, trap b) and would drain the fill ring.  The CALLER waits, with
+// a counted vmcnt and the destination as a "+v" operand of the wait statement (guide 5.7, form ii).
+__device__ __forceinline__ u32x4 load_b128_soff(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+    return v;
+}
+
 // Workgroup part of a conv epilogue's statistics: every wave has stored its per-channel row sums in ITS OWN block of
 // `sst` ([nwaves][2][BQ] floats, zero where a wave has no share); thread t < 2*BQ adds the blocks in wave order (a fixed
 // order, unlike LDS atomics) and publishes one fixed-point add per channel and workgroup.

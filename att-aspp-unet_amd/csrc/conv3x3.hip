@@ -1949,6 +1949,12 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
     // 16-byte epilogue stores (common.h: swap_pair8) when the destination allows them
     const bool wide = ((uintptr_t)a.dst & 15) == 0 && d.dst_pitch % 8 == 0 && (!d.shuffle2x2 || (d.Cout >> 2) % 8 == 0) && !a.nowide;
     int t = 0;
+#ifdef AAU_PW_STAMP
+    // diagnostic build only (scripts/probes/pw_stamp.py): s_memtime stamps of a tile step; a.shift is the debug buffer
+#define PW_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : : "memory")
+    unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_epi = 0, st_steps = 0, st_begin, st_a, st_b;
+    PW_STAMP(st_begin);
+#endif
     // fill cursor: (patch, chunk) of the next tile to issue; the ring runs PD tiles ahead of the multiply
     int fp = first, fc = 0, fb = 0;
     const bool filler = wave < NWF;
@@ -1980,6 +1986,9 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             // tile t must have landed: the younger operations are the fills of tiles t+1 .. t+PD-1 (HL instructions per
             // wave each) and output stores issued between them; waiting down to the fills alone is exact when no store
             // is younger than tile t and at worst also retires a few fills that were issued PD-2 steps ago
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_a);
+#endif
             if constexpr (PD == 1) {
                 if (t > 0 && chunk == 0 && full_tiles && wide) {          // half as many (16-byte) stores per lane
                     if constexpr (NI * MI == 6) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -1998,8 +2007,17 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
                 else if constexpr ((PD - 1) * HL == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             }
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_b); st_wait += st_b - st_a;
+#endif
             __builtin_amdgcn_s_barrier();
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_a); st_bar += st_a - st_b;
+#endif
             issue_next();                        // tile t + PD, into the slot tile t - 1 has just left
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_b); st_issue += st_b - st_a; ++st_steps;
+#endif
             const unsigned short* hbase = sH(cb);
             if (++cb == NBUF) cb = 0;
             {
@@ -2028,10 +2046,17 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
                 __builtin_amdgcn_s_setprio(0);
 #endif
             }
+#ifdef AAU_PW_STAMP
+            asm volatile("" :: "v"(acc[0][0]));
+            PW_STAMP(st_a); st_mfma += st_a - st_b;
+#endif
         }
         // ---- per-patch epilogue ----
         int n, y0, x0;
         patch_origin(patch, n, y0, x0);
+#ifdef AAU_PW_STAMP
+        PW_STAMP(st_a);
+#endif
         if (wide) {
             static_assert(MI % 2 == 0, "pixel rows are stored in pairs");
             const int Co = d.Cout >> 2;
@@ -2088,6 +2113,9 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
                     else if (w[0] == 1.2345f) *(u32x4*)out = pack8(w);
                 }
             }
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_b); st_epi += st_b - st_a;
+#endif
             continue;
         }
 #pragma unroll
@@ -2144,6 +2172,17 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
             }
         }
     }
+#ifdef AAU_PW_STAMP
+    {
+        unsigned long long st_end, rt;
+        PW_STAMP(st_end);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) : : "memory");
+        if (lane == 0 && a.shift) {
+            unsigned long long* o = (unsigned long long*)a.shift + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+            o[0] = st_wait; o[1] = st_bar; o[2] = st_issue; o[3] = st_mfma; o[4] = st_epi; o[5] = st_steps; o[6] = st_end - st_begin; o[7] = rt;
+        }
+    }
+#endif
     if (want_stats) {
         // per-wave row sums (DPP) into the wave's OWN block of LDS, combined in wave order, then one order-independent
         // fixed-point add per channel and workgroup (common.h: stat_add)
@@ -2169,6 +2208,314 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_resw_kernel(const C3Args a, i
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the same kernel with its address arithmetic taken out of the loop.  s_memtime stamps of conv1x1_resw_kernel
+// (profiles/r04_pw_stamp_before.txt; u1.up forward, 92 us) showed that the tile it waits for has always landed (3 % of
+// the loop) and that the time goes into ISSUING things: 21 % in the two LDS-DMA instructions of a step (patch decode with
+// divisions, image-border predicates and 64-bit offsets per piece: 370 cycles per instruction), 37 % in the epilogue
+// (a 64-bit destination address with a division per 16-byte store), 14 % at the barrier where the first four waves wait
+// for the last four; for the accumulating gate gradients 62 % in the epilogue, whose read-modify-write loads queue behind
+// every fill in flight (vmcnt retires in order: each patch drained the ring).  Here
+//   * a piece's per-lane offset is a kernel constant (H, W are multiples of 16: a patch never meets the image border)
+//     and the patch / chunk part travels in the SCALAR offset of the LDS-DMA: a step issues its fills with no vector
+//     arithmetic;
+//   * the stores are buffer stores: per-lane offset constant per (row pair, channel group), patch part scalar;
+//     out-of-range channel groups carry an out-of-range offset, so every lane issues the same number of stores and the
+//     counted waits hold;
+//   * an accumulating destination is loaded at the START of the patch (asm loads hipcc does not count: beside LDS-DMA it
+//     would wait vmcnt(0) for them), lands behind the patch's own MFMA steps and is waited for with a counted vmcnt;
+//   * the step wait counts the loads and the previous patch's stores as young operations instead of waiting them out
+//     (the old count retired three tiles of the ring at every patch start).
+// Wide (16-byte) stores only, NBUF = 7; everything else stays with conv1x1_resw_kernel.
+template <int BQ, int NW, bool ACC>
+__global__ __launch_bounds__(64 * NW) void conv1x1_rs_kernel(const C3Args a, int npatch) {
+    constexpr int NBUF = 7;
+    constexpr int BK = 32, HW_ = 16, NI = BQ / 16, MI = 16 / NW;
+    constexpr int HL = 16 / NW;                      // LDS-DMA instructions per wave and tile
+    constexpr int HALO_E = 256 * BK, WT_E = BQ * BK;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int PD = NBUF - 1;                     // tiles in flight
+    constexpr int L = NI * MI / 2;                   // 16-byte stores (and read-modify-write loads) per lane and patch
+    static_assert(MI == 2 && HL == 2, "eight waves: one row pair per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned short dsm[];   // [NBUF pixel tiles][nchunk weight tiles] | vectors
+    auto sH = [&](int b) -> unsigned short* { return dsm + b * HALO_E; };
+    auto sWt = [&](int chunk) -> unsigned short* { return dsm + NBUF * HALO_E + chunk * WT_E; };
+
+    const aau_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int q0 = blockIdx.y * BQ;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, a.wpk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)a.dst, 0, 0x7fffffff, 0x00020000);
+
+    // ---- weights: all chunk tiles of this channel tile, once ----
+    {
+        const int ntile = a.nchunk;
+        constexpr int PIECES = BQ * 4;
+        for (int base = 0; base < ntile * PIECES; base += 64 * NW) {
+            const int p = base + tid;
+            const int tile = p / PIECES, r = p - tile * PIECES;
+            const int row = r >> 2, lc = swz32(row, r & 3);
+            const bool ok = tile < ntile && q0 + row < d.Cout;
+            const unsigned v = ok ? (unsigned)(((q0 + row) * d.Cpad + tile * BK + lc * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, LDS_PTR(dsm + NBUF * HALO_E + (base + wave * 64) * 8), 16, (int)v, 0, 0, 0);
+        }
+    }
+    // ---- fill roles: per-lane byte offset of (patch row, column, 16-byte part of the chunk) relative to the patch origin ----
+    unsigned vrel[HL], vrel_tail[HL];
+    const int tail_c0 = (a.nchunk - 1) * BK;
+    const bool has_tail = d.Cpad != d.Cin;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+        const int hr = (i * NW + wave) * 16 + (lane >> 2);
+        const int lc = swz32(hr, lane & 3);
+        vrel[i] = (unsigned)((((hr / HW_) * d.W + (hr % HW_)) * d.src_pitch + lc * 8) * 2);
+        vrel_tail[i] = (tail_c0 + lc * 8 < d.Cin) ? vrel[i] : OOB;
+    }
+    auto patch_origin = [&](int patch, int& n, int& y0, int& x0) {
+        if (a.rev) patch = npatch - 1 - patch;
+        const int px_t = patch % a.tiles_x;
+        const int t2 = patch / a.tiles_x;
+        const int py_t = t2 % a.tiles_y;
+        n = t2 / a.tiles_y; y0 = py_t * 16; x0 = px_t * 16;
+    };
+    auto src_base = [&](int patch) -> unsigned {
+        int n, y0, x0;
+        patch_origin(patch, n, y0, x0);
+        return (unsigned)((((n * d.H + y0) * d.W + x0) * d.src_pitch) * 2);
+    };
+
+    // per-channel epilogue vectors (bias, folded-BN scale / shift) in LDS behind the ROUNDED weight area
+    float* par = (float*)((unsigned char*)dsm + NBUF * HALO_E * 2 + ((size_t)a.nchunk * BQ * 64 + 8191) / 8192 * 8192);   // [3][BQ]
+    if (a.bias || a.scale) {
+        const int Co_ = d.shuffle2x2 ? d.Cout >> 2 : d.Cout;
+        for (int i = tid; i < BQ; i += 64 * NW) {
+            const int q = q0 + i;
+            const int qv = q < d.Cout ? (d.shuffle2x2 ? q % Co_ : q) : 0;
+            par[i] = a.bias ? a.bias[qv] : 0.f;
+            par[BQ + i] = a.scale ? a.scale[qv] : 1.f;
+            par[2 * BQ + i] = a.scale ? a.shift[qv] : 0.f;
+        }
+        __syncthreads();
+    }
+    const bool want_stats = a.stats != nullptr;
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[ni][r] = s2[ni][r] = 0.f;
+
+    // ---- store roles: after the cross-lane swap this lane owns channels qw .. qw + 7 of the pixel (row + (fk & 1), fr) ----
+    unsigned evo[NI];
+    const int Co = d.Cout >> 2;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int qw = q0 + ni * 16 + 8 * (fk >> 1);
+        const int row = wave * MI + (fk & 1);
+        if (qw >= d.Cout) evo[ni] = OOB;
+        else if (d.shuffle2x2) {
+            const int pos = qw / Co;
+            evo[ni] = (unsigned)((((2 * row + (pos >> 1)) * (2 * d.W) + 2 * fr + (pos & 1)) * d.dst_pitch + (qw - pos * Co)) * 2);
+        } else {
+            evo[ni] = (unsigned)(((row * d.W + fr) * d.dst_pitch + qw) * 2);
+        }
+    }
+    auto dst_base = [&](int patch) -> unsigned {
+        int n, y0, x0;
+        patch_origin(patch, n, y0, x0);
+        if (d.shuffle2x2) return (unsigned)((((n * 2 * d.H + 2 * y0) * (2 * d.W) + 2 * x0) * d.dst_pitch) * 2);
+        return (unsigned)((((n * d.H + y0) * d.W + x0) * d.dst_pitch) * 2);
+    };
+
+    const int first = blockIdx.x, stride = gridDim.x;
+#ifdef AAU_PW_STAMP
+    // diagnostic build only (scripts/probes/pw_stamp.py): s_memtime stamps of a tile step; a.shift is the debug buffer
+#define PW_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : : "memory")
+    unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_epi = 0, st_steps = 0, st_begin, st_a, st_b;
+    PW_STAMP(st_begin);
+#endif
+    // fill cursor: (patch, chunk) of the next tile to issue; the ring runs PD tiles ahead of the multiply
+    int fp = first, fc = 0, fb = 0;
+    unsigned fbase = fp < npatch ? src_base(fp) : 0u;
+    auto issue_next = [&]() {
+        const bool live = fp < npatch;                // past the end: out-of-range pieces keep the instruction count the same
+        const bool last = has_tail && fc == a.nchunk - 1;
+        const unsigned soff = live ? fbase + (unsigned)(fc * BK * 2) : 0u;
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+            const unsigned v = live ? (last ? vrel_tail[i] : vrel[i]) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sH(fb) + (i * NW + wave) * 16 * BK), 16, (int)v, (int)soff, 0, 0);
+        }
+        if (++fc == a.nchunk) {
+            fc = 0; fp += stride;
+            if (fp < npatch) fbase = src_base(fp);
+        }
+        if (++fb == NBUF) fb = 0;
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue_next();
+    int cb = 0;                                  // ring slot of tile t
+    for (int patch = first; patch < npatch; patch += stride) {
+        const unsigned ebase = dst_base(patch);
+        // an accumulating destination: fetched now, behind the stores of the previous patch and in front of this patch's
+        // fills -- it lands while the chunks are multiplied
+        u32x4 old[NI];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) old[ni] = load_b128_soff(rsD, evo[ni], ebase);
+        }
+        f32x4 acc[NI][MI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+            // tile t has landed when all but the operations YOUNGER than its fills are done: the fills of tiles t+1 .. t+PD-1
+            // ((PD - 1) * HL), this patch's L loads (issued less than PD steps ago: nchunk <= PD) and the previous patch's L
+            // stores (issued one step before them)
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_a);
+#endif
+            if constexpr (ACC) {
+                if (patch != first) asm volatile("s_waitcnt vmcnt(%0)" : : "i"((PD - 1) * HL + 2 * L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" : : "i"((PD - 1) * HL + L) : "memory");
+            } else {
+                if (patch != first) asm volatile("s_waitcnt vmcnt(%0)" : : "i"((PD - 1) * HL + L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" : : "i"((PD - 1) * HL) : "memory");
+            }
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_b); st_wait += st_b - st_a;
+#endif
+            __builtin_amdgcn_s_barrier();
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_a); st_bar += st_a - st_b;
+#endif
+            issue_next();                        // tile t + PD, into the slot tile t - 1 has just left
+#ifdef AAU_PW_STAMP
+            PW_STAMP(st_b); st_issue += st_b - st_a; ++st_steps;
+#endif
+            const unsigned short* hbase = sH(cb);
+            if (++cb == NBUF) cb = 0;
+            const unsigned short* wbase = sWt(chunk);
+            bf16x8 wf[NI], af[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = ni * 16 + fr;
+                wf[ni] = *(const bf16x8*)(wbase + row * BK + swz32(row, fk) * 8);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int hr = (wave * MI + mi) * HW_ + fr;
+                af[mi] = *(const bf16x8*)(hbase + hr * BK + swz32(hr, fk) * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = AAU_MFMA16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#ifdef AAU_PW_STAMP
+            asm volatile("" :: "v"(acc[0][0]));
+            PW_STAMP(st_a); st_mfma += st_a - st_b;
+#endif
+        }
+        // ---- per-patch epilogue ----
+#ifdef AAU_PW_STAMP
+        PW_STAMP(st_a);
+#endif
+        if constexpr (ACC) {
+            // the loads are older than the nchunk * HL fills issued since
+            // (the counted wait names no registers: a switch over asm statements with "+v" operands makes hipcc copy the
+            //  loaded registers in front of the wait.  The empty statement behind it pins the first read of old[] below.)
+            switch (a.nchunk) {
+                case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            }
+            static_assert(NI == 3 || NI == 6, "operand list below");
+            if constexpr (NI == 6) asm volatile("" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3 % NI]), "+v"(old[4 % NI]), "+v"(old[5 % NI]) : : "memory");
+            else asm volatile("" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]) : : "memory");
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int q = q0 + ni * 16 + 4 * fk;
+            float va[4], vb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[r] = acc[ni][0][r]; vb[r] = acc[ni][1][r]; }
+            if (q < d.Cout) {
+                if (want_stats) { epi_stats(a, 0, q, va, s1[ni], s2[ni]); epi_stats(a, 0, q, vb, s1[ni], s2[ni]); }
+                const int ql = ni * 16 + 4 * fk;
+                if (a.bias) {
+                    const f32x4 b = *(const f32x4*)(par + ql);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { va[r] += b[r]; vb[r] += b[r]; }
+                }
+                if (a.scale) {
+                    const f32x4 sc = *(const f32x4*)(par + BQ + ql);
+                    const f32x4 sh = *(const f32x4*)(par + 2 * BQ + ql);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { va[r] = va[r] * sc[r] + sh[r]; vb[r] = vb[r] * sc[r] + sh[r]; }
+                }
+            }
+            float w[8];
+            swap_pair8(va, vb, w);                            // every lane takes part
+            if constexpr (ACC) {
+                float o[8];
+                unpack8(old[ni], o);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) w[r] += o[r];
+            }
+            if (d.relu) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) w[r] = fmaxf(w[r], 0.f);
+            }
+            store_b128_soff(pack8(w), rsD, evo[ni], ebase);
+        }
+#ifdef AAU_PW_STAMP
+        PW_STAMP(st_b); st_epi += st_b - st_a;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AAU_PW_STAMP
+    {
+        unsigned long long st_end, rt;
+        PW_STAMP(st_end);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) : : "memory");
+        if (lane == 0 && a.shift) {
+            unsigned long long* o = (unsigned long long*)a.shift + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+            o[0] = st_wait; o[1] = st_bar; o[2] = st_issue; o[3] = st_mfma; o[4] = st_epi; o[5] = st_steps; o[6] = st_end - st_begin; o[7] = rt;
+        }
+    }
+#undef PW_STAMP
+#endif
+    if (want_stats) {
+        float* sst = (float*)dsm;                      // [NW][2][BQ]
+        __syncthreads();
+        for (int i = tid; i < NW * 2 * BQ; i += (int)blockDim.x) sst[i] = 0.f;
+        __syncthreads();
+        float* mine = sst + wave * 2 * BQ;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = row16_sum(s1[ni][r]), x2 = row16_sum(s2[ni][r]);
+                if (fr == 0) {
+                    mine[ni * 16 + 4 * fk + r] = x1;
+                    mine[BQ + ni * 16 + 4 * fk + r] = x2;
+                }
+            }
+        }
+        __syncthreads();
+        stats_publish(sst, NW, BQ, tid, q0, d.Cout, (long long*)a.stats, (int)(blockIdx.x % AAU_STAT_REPLICAS));
+    }
+}
 
 // true when the resident-weight 1x1 kernel applies (high-resolution 1x1 convs with a small weight matrix)
 bool conv1x1_resw_applicable(const aau_conv_desc* d, bool want_stats) {
@@ -2221,11 +2568,18 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
         if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
         hipLaunchKernelGGL(kern, dim3(gx, ntq), dim3(512), lds, s, a, npatch);
     };
+    // round 4's form (scalar-offset fills and stores, prefetched read-modify-write): 16-byte stores, the 7-tile ring, every
+    // tensor below 2 GiB, at most 6 chunks (the loads of a patch must stay younger than the tile a step waits for)
+    const int64_t Mo = (int64_t)d->N * d->H * d->W * (d->shuffle2x2 ? 4 : 1);
+    const bool wide_ok = ((uintptr_t)dst & 15) == 0 && d->dst_pitch % 8 == 0 && (!d->shuffle2x2 || (d->Cout >> 2) % 8 == 0) && !a.nowide;
+    const bool rs = nbuf == 7 && wide_ok && a.nchunk <= 6 && Mo * d->dst_pitch * 2 < 0x7fffffff && !getenv("AAU_PW_OLD");
     if (BQ == 48) {
-        if (nbuf == 7) go(conv1x1_resw_kernel<48, 8, 7>);
+        if (rs) { if (d->accumulate) go(conv1x1_rs_kernel<48, 8, true>); else go(conv1x1_rs_kernel<48, 8, false>); }
+        else if (nbuf == 7) go(conv1x1_resw_kernel<48, 8, 7>);
         else go(conv1x1_resw_kernel<48, 8, 2>);
     } else {
-        if (nbuf == 7) go(conv1x1_resw_kernel<96, 8, 7>);
+        if (rs) { if (d->accumulate) go(conv1x1_rs_kernel<96, 8, true>); else go(conv1x1_rs_kernel<96, 8, false>); }
+        else if (nbuf == 7) go(conv1x1_resw_kernel<96, 8, 7>);
         else go(conv1x1_resw_kernel<96, 8, 2>);
     }
 #ifdef AAU_C3S_ABLATE

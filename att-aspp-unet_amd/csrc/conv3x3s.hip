@@ -36,19 +36,6 @@ __device__ __forceinline__ void wait_vm_s() {
     else static_assert(N == 0, "add the immediate");
 }
 
-// 16-byte buffer store with the row part of the address in the SCALAR offset.  gfx950 reads the four data registers of a
-// buffer_store_dwordx4 AFTER the instruction has issued: a vector instruction that rewrites them in the next cycle reaches
-// the store (seen here: dword 0 of lanes 12-15 of every row of 16 carried the NEXT accumulator pair's raw fp32 bits).
-// hipcc pads that hazard itself only when the scalar offset is NOT a register (LLVM GCNHazardRecognizer::
-// createsVALUHazard: "this hazard only exists if the instruction is not using a register in the soffset field"), so with
-// the builtin + register soffset the emitted code had a v_mov into the data register directly behind the store -- wrong
-// outputs whenever instruction fetch lets the two issue back to back (it came and went with code placement; round 3 took
-// it for a miscounted vmcnt).  The store is therefore issued from an asm statement that carries its own wait states.
-// (An asm store is not in hipcc's vmcnt bookkeeping: every wait that depends on these stores is hand-counted, NST below.)
-__device__ __forceinline__ void store_b128_soff(u32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
-}
-
 // Epilogue of one pair of accumulator quads (c3args.h: epi_pair_wide) with the store as a buffer store: statistics, bias,
 // folded-BN affine (staged in LDS as [3][96] floats bias | scale | shift; par = this lane's channel quad in it) in the MFMA layout, the cross-lane swap, ReLU, one
 // 16-byte store at rsD[voff + soff].

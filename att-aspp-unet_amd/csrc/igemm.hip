@@ -162,7 +162,7 @@ static int conv_prepare(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     AAU_REQUIRE((int64_t)d->N * d->H * d->W < 0x7fffffff && (int64_t)d->N * d->Ho * d->Wo < 0x7fffffff,
                 "aau_conv_igemm: pixel count overflows int32");
 #ifndef ABL_STAMP
-#ifndef AAU_IGEMM_STAMP      /* the diagnostic build takes its stamp buffer through `shift` */
+#if !defined(AAU_IGEMM_STAMP) && !defined(AAU_PW_STAMP)      /* the diagnostic builds take their stamp buffer through `shift` */
     AAU_REQUIRE((scale == nullptr) == (shift == nullptr), "aau_conv_igemm: scale and shift come together");
 #endif
 #endif

@@ -784,7 +784,13 @@ class Plan:
                 else:
                     f.add("aau_conv_igemm", dg, cat[:, Co:], wg.pk_f, zg, None, None, None, sg_)
                     f.add("aau_conv_igemm", dx, skips[lv], wx.pk_f, zx, None, None, None, sx_)
-                if tr:
+                if tr and not eng.no_bn_multi and bg.C == bx.C:
+                    # the statistics of the gate's two 1x1 convs: one launch
+                    tabF = ops.ptr_table([[w_["stats"], bn_.gamma, bn_.beta, bn_.rm, bn_.rv, bn_.nbt, w_["scale"], w_["shift"],
+                                           w_["mean"], w_["invstd"]] for bn_, w_ in ((bg, wgb), (bx, wxb))])
+                    f.keep.extend([tabF, bg.rm, bg.rv, bg.nbt, bx.rm, bx.rv, bx.nbt])
+                    f.add("aau_bn_finalize_multi", 2, tabF, ops.stat_words(bg.C) * 8, bg.C, Mo, 1e-5, 0.1)
+                elif tr:
                     self._bn_finalize(bg, wgb, Mo)
                     self._bn_finalize(bx, wxb, Mo)
                 else:
