@@ -85,6 +85,7 @@ _SIGS = {
     "aau_conv1_fwd": [P, P, P, P, L, I, I, I, I, P],
     "aau_conv1_wgrad": [P, P, P, I, I, I, I, P],
     "aau_pack_weights": [P, P, P, I, L, P],
+    "aau_zero_multi": [P, P, I, P, C.c_uint64, P],
     "aau_bn_finalize": [P, L, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
     "aau_bn_fold_eval": [P, P, P, P, P, P, I, F, P],
     "aau_bn_act": [P, I, P, I, P, P, L, I, I, L, F, P, P],

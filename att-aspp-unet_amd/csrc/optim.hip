@@ -109,10 +109,18 @@ __global__ void step_inc_kernel(const float* norm_ws, int64_t* step_dev) {
 // s_c == 1 (two 16-B loads per thread), row-fastest otherwise (the transposed data-gradient operands).
 __global__ __launch_bounds__(256) void pack_kernel(const float* flat, unsigned short* packed,
                                                    const aau_pack_entry* table, int n_entries) {
-    int e = 0;
+    // entry of this workgroup = number of entries that begin at or before it, minus one: counted by the whole workgroup
+    // (the serial walk over the table was a chain of up to n_entries dependent loads per workgroup: 64 us per step)
     const int64_t blk = blockIdx.x;
-    while (e + 1 < n_entries && table[e + 1].blk_begin <= blk) ++e;
-    const aau_pack_entry ent = table[e];
+    int cnt = 0;
+    for (int k = threadIdx.x; k < n_entries; k += 256) cnt += table[k].blk_begin <= blk ? 1 : 0;
+    __shared__ int s_cnt[4];
+    int wsum = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_down(wsum, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    const aau_pack_entry ent = table[s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] - 1];
     const unsigned C8 = ent.Cpad >> 3;
     const unsigned total = (unsigned)ent.R * ent.T * C8;
     const unsigned i = (unsigned)(blk - ent.blk_begin) * 256u + threadIdx.x;
@@ -144,6 +152,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* flat, unsigned s
         for (int j = 0; j < 8; ++j) v[j] = (c0 + j < ent.C) ? flat[off + (int64_t)(c0 + j) * ent.s_c] : 0.f;
     }
     *(u32x4*)(packed + ent.dst_off + ((int64_t)r * ent.T + t) * ent.Cpad + c0) = pack8(v);
+}
+
+// Up to 8 buffers cleared in ONE launch (blockIdx.y = buffer), plus an optional 64-bit counter bumped by `inc`: the
+// step's per-pass housekeeping (statistics / reduction arenas, the flat gradient, the dropout seed) was five ATen fills.
+struct ZeroMulti { void* p[8]; long long n16[8]; };
+__global__ __launch_bounds__(256) void zero_multi_kernel(const ZeroMulti z, unsigned long long* counter, unsigned long long inc) {
+    if (counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *counter += inc;
+    u32x4* q = (u32x4*)z.p[blockIdx.y];
+    const long long n = z.n16[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) q[i] = u32x4{0u, 0u, 0u, 0u};
 }
 
 }  // namespace aau
@@ -201,4 +219,27 @@ extern "C" int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_p
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, flat, packed,
                        table_dev, n_entries);
     return check_launch("aau_pack_weights");
+}
+
+extern "C" int aau_zero_multi(void* const* bufs, const int64_t* bytes, int n, uint64_t* counter, uint64_t counter_inc,
+                              void* stream) {
+    AAU_REQUIRE(n >= 0 && n <= 8 && (n == 0 || (bufs && bytes)), "aau_zero_multi: %d buffers (at most 8)", n);
+    AAU_REQUIRE(n > 0 || counter, "aau_zero_multi: nothing to do");
+    ZeroMulti z;
+    long long most = 1;
+    for (int i = 0; i < 8; ++i) { z.p[i] = nullptr; z.n16[i] = 0; }
+    for (int i = 0; i < n; ++i) {
+        AAU_REQUIRE(bufs[i] && bytes[i] > 0 && bytes[i] % 16 == 0 && ((uintptr_t)bufs[i] & 15) == 0,
+                    "aau_zero_multi: buffer %d must be 16-byte aligned with a size that is a multiple of 16 (%lld)", i,
+                    (long long)bytes[i]);
+        z.p[i] = bufs[i];
+        z.n16[i] = bytes[i] / 16;
+        if (z.n16[i] > most) most = z.n16[i];
+    }
+    long long blocks = (most + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    ProfScope prof(3, 0, (hipStream_t)stream);
+    hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)blocks, (unsigned)(n > 0 ? n : 1)), dim3(256), 0, (hipStream_t)stream, z,
+                       (unsigned long long*)counter, (unsigned long long)counter_inc);
+    return check_launch("aau_zero_multi");
 }

@@ -184,14 +184,14 @@ class _Arena:
 
     def __init__(self, n, device, dtype=F32):
         self.device, self.dtype = device, dtype
-        self.grow = max(int(n), 16)
+        self.grow = _ru(max(int(n), 16), 4)       # whole 16-byte units: the arenas are cleared by aau_zero_multi
         self.bufs = [torch.zeros(self.grow, dtype=dtype, device=device)]
         self.off = 0
 
     def take(self, n):
         n4 = _ru(int(n), 4)
         if self.off + n4 > self.bufs[-1].numel():
-            self.bufs.append(torch.zeros(max(self.grow, n4), dtype=self.dtype, device=self.device))
+            self.bufs.append(torch.zeros(max(self.grow, n4), dtype=self.dtype, device=self.device))   # n4: multiple of 4
             self.off = 0
         t = self.bufs[-1][self.off:self.off + n]
         self.off += n4
@@ -1047,8 +1047,9 @@ class Plan:
             self.x.copy_(x.reshape(self.x.shape), non_blocking=True)
         if self.train:
             self.fwd_gen += 1
-            self.stats_arena.zero_()
-            self.drop_seed.add_(0x9E3779B97F4A7C15 - (1 << 64))   # odd increment mod 2^64: a new mask every step
+            # one launch: the statistic accumulators cleared, the dropout seed advanced by an odd increment mod 2^64
+            # (a new mask every step)
+            ops.zero_multi(self.stats_arena.bufs, self.drop_seed, 0x9E3779B97F4A7C15)
         self.fwd.run(stream)
         return self.logits
 
@@ -1056,9 +1057,7 @@ class Plan:
         st = self.eng.store
         if dlogits is not None and dlogits.data_ptr() != self.dlogits.data_ptr():
             self.dlogits.copy_(dlogits.reshape(self.dlogits.shape), non_blocking=True)
-        self.red_arena.zero_()
-        self.bstats_arena.zero_()
-        st.gflat.zero_()
+        ops.zero_multi(self.red_arena.bufs + self.bstats_arena.bufs + [st.gflat])
 
     def run_backward(self, dlogits: torch.Tensor | None):
         stream = torch.cuda.current_stream().cuda_stream

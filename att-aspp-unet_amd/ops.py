@@ -270,6 +270,21 @@ def pack_weights(flat, packed, table_dev, n_entries, total_blocks):
           "aau_pack_weights")
 
 
+def zero_multi(tensors, counter=None, counter_inc=0):
+    """Clears the given device tensors in one launch (groups of 8) and bumps an int64 counter tensor (aau.h: aau_zero_multi)."""
+    import ctypes as C
+    tensors = list(tensors)
+    first = True
+    while tensors or (first and counter is not None):
+        chunk, tensors = tensors[:8], tensors[8:]
+        ptrs = (C.c_void_p * 8)(*[t.data_ptr() for t in chunk])
+        sizes = (C.c_int64 * 8)(*[t.numel() * t.element_size() for t in chunk])
+        cp = counter.data_ptr() if (first and counter is not None) else None
+        check(fn("aau_zero_multi")(ptrs, sizes, len(chunk), cp, int(counter_inc) & 0xFFFFFFFFFFFFFFFF, _stream()),
+              "aau_zero_multi")
+        first = False
+
+
 def bn_finalize(stats, gamma, beta, rmean, rvar, nbt, scale, shift, smean, sinvstd, Cc, count,
                 eps=1e-5, momentum=0.1):
     _check_stats(stats, Cc, "bn_finalize")

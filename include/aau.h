@@ -240,6 +240,12 @@ typedef struct aau_pack_entry {
 int aau_pack_weights(const float* flat, aau_bf16* packed, const aau_pack_entry* table_dev,
                      int n_entries, int64_t total_blocks, void* stream);
 
+/* Clears up to 8 device buffers (16-byte aligned, sizes multiples of 16) in one launch and, when `counter` is not */
+/* NULL, adds counter_inc (mod 2^64) to the 64-bit word it points to: the per-pass housekeeping of a training step */
+/* (statistic / reduction workspaces, the flat gradient, the dropout seed chain of the reference's nn.Dropout,     */
+/* att_aspp_unet_pipeline.py:78) that would otherwise be one fill per buffer.                                       */
+int aau_zero_multi(void* const* bufs, const int64_t* bytes, int n, uint64_t* counter, uint64_t counter_inc, void* stream);
+
 /* ---- BatchNorm2d (pipeline:64 and every BN of :71-90) -------------------------------- */
 /* training: stats replicas -> mean / biased var -> scale = g*invstd, shift = b-mean*scale; */
 /* saves mean, invstd; running stats: momentum 0.1, unbiased var; nbt += 1.              */
