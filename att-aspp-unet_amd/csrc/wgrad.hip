@@ -390,7 +390,7 @@ int wgrad3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16*
 // wgrad3x3r.hip
 int wgrad3x3r_variant(const aau_conv_desc* d);
 int wgrad3x3r_launch(int variant, const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
-                     int64_t ws_bytes, int64_t* need, hipStream_t s);
+                     int64_t ws_bytes, int64_t* need, hipStream_t s, const float* in_scale = nullptr, const float* in_shift = nullptr);
 
 template <int TQ, int TC>
 static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
@@ -472,8 +472,7 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
                     "aau_conv_wgrad: src_split_c / src_split_off must be multiples of 8 inside the channel range");
     }
     if (in_scale)
-        AAU_REQUIRE(wgrad3x3_applicable(d) && !split && wgrad3x3r_variant(d) == 0,
-                    "aau_conv_wgrad_bnin: descriptor not served (aau_conv_wgrad_bnin_ok)");
+        AAU_REQUIRE(aau_conv_wgrad_bnin_ok(d), "aau_conv_wgrad_bnin: descriptor not served (aau_conv_wgrad_bnin_ok)");
     if (wgrad3x3_applicable(d)) {
         const int rv = split ? 0 : wgrad3x3r_variant(d);
         if (need) return rv ? wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, need, (hipStream_t)stream)
@@ -483,7 +482,7 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
         if (rv) {
             prof_tag(rv == 1 ? "wgrad3x3r<3,4>" : "wgrad3x3r<6,2>",
                      2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout) + 4.0 * d->Cout * 9.0 * d->Cin);
-            return wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream);
+            return wgrad3x3r_launch(rv, d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream, in_scale, in_shift);
         }
         prof_tag("wgrad3x3<3,8>", 2.0 * ((double)d->N * d->H * d->W * d->Cin + (double)a.M * d->Cout) + 4.0 * d->Cout * 9.0 * d->Cin);
         return wgrad3x3_launch(d, src, dz, dw, ws, ws_bytes, nullptr, (hipStream_t)stream, in_scale, in_shift);
@@ -518,7 +517,8 @@ extern "C" int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes) {
 extern "C" int aau_conv_wgrad_bnin_ok(const aau_conv_desc* d) {
     using namespace aau;
     if (!d || getenv("AAU_NO_BNIN")) return 0;
-    return wgrad3x3_applicable(d) && d->src_split_c <= 0 && d->dst_split_c <= 0 && wgrad3x3r_variant(d) == 0 &&
+    const int rv = wgrad3x3r_variant(d);        // 0: wgrad3x3 (48 x 48 tiles), 2: the 96 x 32 row-reuse tiling
+    return wgrad3x3_applicable(d) && d->src_split_c <= 0 && d->dst_split_c <= 0 && (rv == 0 || rv == 2) &&
            d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->src_pitch % 8 == 0 && d->dst_pitch % 8 == 0;
 }
 

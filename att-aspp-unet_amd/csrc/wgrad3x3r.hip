@@ -39,6 +39,8 @@ struct W3RArgs {
     int tiles_x, tiles_y;        // W/16, H/8
     int rev;
     int noremap;                 // experiment (AAU_W3_NOREMAP): the round-1 order, split fastest, no XCD remap
+    const float* in_scale;       // BNIN: x = relu(src * in_scale + in_shift) applied on the halo tile in LDS (per Cin channel)
+    const float* in_shift;
 };
 
 #define AAU_TR16O(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
@@ -47,7 +49,11 @@ struct W3RArgs {
 // staging buffers, combined through LDS (group 1 -> group 0, a fixed order) before the slab leaves.  The same eight
 // waves per CU as two KG = 1 workgroups, but half as many split-K slabs: every launch used to write 56 MB of partial
 // sums (512 workgroups x 110 KB, whatever the layer) that wg_reduce_kernel read back.
-template <int QT, int CJ, int KG>
+// BNIN (round 4, aau_conv_wgrad_bnin): the source is the producing layer's RAW conv output and relu(z * scale + shift) is
+// applied on the halo tile in LDS: each lane rewrites the 16-byte pieces ITS OWN LDS-DMA fetched, behind the vmcnt wait
+// that says they have landed and in front of the barrier that publishes the tile -- in the LOAD half of the ping-pong,
+// while the other group multiplies.  Pieces outside the image stay zero (the padding of the ACTIVATION, not of z).
+template <int QT, int CJ, int KG, bool BNIN = false>
 __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a) {
     static_assert(CJ * (QT / 3) == 4 && QT % 3 == 0, "four waves: CJ channel groups x QT/3 q groups");
     constexpr int BQ = QT * 16, BC = CJ * 16;
@@ -127,6 +133,19 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
         xhx[i] = hx;
         xch[i] = ch;
     }
+    // BNIN: all pieces of a lane carry the SAME eight channels (slot = lane % XS and the swizzle bit come from the lane
+    // alone: the piece stride 256 is a multiple of 8 pixels x XS slots), so one scale / shift octet per lane serves them
+    float bsc[8], bsh[8];
+    unsigned xv0 = 0, xv1 = 0;          // valid bits of the pieces last staged into buffer 0 / 1
+    if constexpr (BNIN) {
+        static_assert((256 / XS) % 8 == 0, "the pieces of a lane share their channel octet");
+        const bool okc = xch[0] < d.Cin;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bsc[j] = okc ? a.in_scale[xch[0] + j] : 0.f;
+            bsh[j] = okc ? a.in_shift[xch[0] + j] : 0.f;
+        }
+    }
 
     auto stage = [&](int buf, int patch) {
         const int pxi = patch % a.tiles_x;
@@ -142,12 +161,33 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
             const unsigned v = (live && yrel[i] >= 0) ? (unsigned)((org * d.dst_pitch + yrel[i]) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sy + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
         }
+        unsigned vb = 0;
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
             const int y = y0 - 1 + xhy[i], x = x0 - 1 + xhx[i];
             const bool ok = live && (unsigned)y < (unsigned)d.H && (unsigned)x < (unsigned)d.W;
             const unsigned v = ok ? (unsigned)((((n * d.H + y) * d.W + x) * d.src_pitch + xch[i]) * 2) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sy + YB + (i * 4 + wave) * 1024), 16, (int)v, 0, 0, 0);
+            if (ok) vb |= 1u << i;
+        }
+        if constexpr (BNIN) { if (buf == 0) xv0 = vb; else xv1 = vb; }
+    };
+    // BNIN: relu(z * scale + shift) on this lane's pieces of buffer `buf` (they have landed: the caller's vmcnt wait)
+    auto xform = [&](const int buf) __attribute__((always_inline)) {
+        if constexpr (BNIN) {
+            const unsigned vb = buf == 0 ? xv0 : xv1;
+#pragma unroll
+            for (int i = 0; i < NLX; ++i) {
+                if ((vb >> i) & 1u) {
+                    u32x4* q = (u32x4*)(smem + buf * STAGE + YB + (i * 4 + wave) * 1024 + lane * 16);
+                    float f[8];
+                    unpack8(*q, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * bsc[j] + bsh[j], 0.f);
+                    *q = pack8(f);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the rewritten pieces are in LDS before the barrier
         }
     };
 
@@ -247,12 +287,14 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
             stage(0, patch);
             stage(1, patch + KG);
             asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            xform(0);
             while (true) {
                 __builtin_amdgcn_s_barrier();
                 compute(0);
                 __builtin_amdgcn_s_barrier();
                 stage(0, patch + 2 * KG);
-                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");      // buffer 1 (staged a trip ago) has landed
+                xform(1);
                 patch += KG;
                 if (++k == ntrip) break;
                 __builtin_amdgcn_s_barrier();
@@ -260,6 +302,7 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
                 __builtin_amdgcn_s_barrier();
                 stage(1, patch + 2 * KG);
                 asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                xform(0);
                 patch += KG;
                 if (++k == ntrip) break;
             }
@@ -268,7 +311,8 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
             while (true) {
                 __builtin_amdgcn_s_barrier();
                 stage(1, patch + KG);
-                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(9)" ::: "memory");      // buffer 0 has landed
+                xform(0);
                 __builtin_amdgcn_s_barrier();
                 compute(0);
                 patch += KG;
@@ -276,6 +320,7 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
                 __builtin_amdgcn_s_barrier();
                 stage(0, patch + KG);
                 asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                xform(1);
                 __builtin_amdgcn_s_barrier();
                 compute(1);
                 patch += KG;
@@ -286,6 +331,7 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
     } else {
     stage(0, patch);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xform(0);
     __builtin_amdgcn_s_barrier();
     while (true) {
         bool more = k + 1 < ntrip;
@@ -293,6 +339,7 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
         compute(0);
         if (!more) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform(1);
         __builtin_amdgcn_s_barrier();
         patch += KG; ++k;
         more = k + 1 < ntrip;
@@ -300,6 +347,7 @@ __global__ __launch_bounds__(256 * KG, 2) void wgrad3x3r_kernel(const W3RArgs a)
         compute(1);
         if (!more) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform(0);
         __builtin_amdgcn_s_barrier();
         patch += KG; ++k;
     }
@@ -368,7 +416,7 @@ int wgrad3x3r_variant(const aau_conv_desc* d) {
     return 0;
 }
 
-template <int QT, int CJ, int KG>
+template <int QT, int CJ, int KG, bool BNIN = false>
 static int launch_w3r(W3RArgs& a, const aau_conv_desc* d, float* ws, int64_t ws_bytes, int64_t* need, hipStream_t s) {
     constexpr int BQ = QT * 16, BC = CJ * 16;
     constexpr int YB = ((128 * (BQ / 8) + 255) / 256) * 4096, XB = ((180 * CJ * 2 + 255) / 256) * 4096;
@@ -399,11 +447,11 @@ static int launch_w3r(W3RArgs& a, const aau_conv_desc* d, float* ws, int64_t ws_
     a.noremap = getenv("AAU_W3_NOREMAP") ? 1 : 0;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)wgrad3x3r_kernel<QT, CJ, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)wgrad3x3r_kernel<QT, CJ, KG, BNIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     static_assert(KG == 1 || KG * 2 * (YB + XB) >= 27 * 256 * 16, "the combine needs 27 x 256 float4 of LDS");
-    hipLaunchKernelGGL((wgrad3x3r_kernel<QT, CJ, KG>), dim3((unsigned)grid), dim3(256 * KG), KG * 2 * (YB + XB), s, a);
+    hipLaunchKernelGGL((wgrad3x3r_kernel<QT, CJ, KG, BNIN>), dim3((unsigned)grid), dim3(256 * KG), KG * 2 * (YB + XB), s, a);
     if (!ws) return check_launch("aau_conv_wgrad(3x3 row reuse)");
     WRedArgs r;
     r.ws = ws; r.dw = a.dw;
@@ -414,9 +462,11 @@ static int launch_w3r(W3RArgs& a, const aau_conv_desc* d, float* ws, int64_t ws_
 }
 
 int wgrad3x3r_launch(int variant, const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
-                     int64_t ws_bytes, int64_t* need, hipStream_t s) {
+                     int64_t ws_bytes, int64_t* need, hipStream_t s, const float* in_scale, const float* in_shift) {
     W3RArgs a;
     a.d = *d;
+    a.in_scale = in_scale; a.in_shift = in_shift;
+    if (in_scale && variant != 2) { set_error("aau_conv_wgrad_bnin: only the 96 x 32 row-reuse tiling applies BatchNorm on load"); return AAU_E_INVALID; }
     a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
     const int64_t npix = (int64_t)d->N * d->H * d->W;
     const int64_t sb = ((npix - 1) * d->src_pitch + d->Cin) * 2, zb = ((npix - 1) * d->dst_pitch + d->Cout) * 2;
@@ -429,6 +479,7 @@ int wgrad3x3r_launch(int variant, const aau_conv_desc* d, const aau_bf16* src, c
     const int BQv = variant == 1 ? 48 : 96, BCv = variant == 1 ? 64 : 32;
     const int64_t tiles_v = (int64_t)((d->Cout + BQv - 1) / BQv) * ((d->Cin + BCv - 1) / BCv);
     const bool kg1 = kg1env || (256 / tiles_v) * tiles_v < 230;
+    if (in_scale) return kg1 ? launch_w3r<6, 2, 1, true>(a, d, ws, ws_bytes, need, s) : launch_w3r<6, 2, 2, true>(a, d, ws, ws_bytes, need, s);
     if (kg1) {
         if (variant == 1) return launch_w3r<3, 4, 1>(a, d, ws, ws_bytes, need, s);
         return launch_w3r<6, 2, 1>(a, d, ws, ws_bytes, need, s);

@@ -724,7 +724,10 @@ def test_strip_kernel_with_batchnorm_relu_applied_on_the_input(ops, case):
     assert torch.equal(out2.view(torch.int16), ref.view(torch.int16))
 
 
-@pytest.mark.parametrize("case", [(2, 32, 48, 48, 48), (1, 64, 16, 48, 48), (3, 16, 80, 48, 48)])
+@pytest.mark.parametrize("case", [(2, 32, 48, 48, 48), (1, 64, 16, 48, 48), (3, 16, 80, 48, 48),
+                                  # the 96 x 32 row-reuse tiling (wgrad3x3r<6,2>): two ping-pong groups, an odd patch count per
+                                  # group, and the one-group form (90 tiles)
+                                  (2, 32, 48, 96, 96), (3, 24, 16, 64, 96), (1, 16, 16, 960, 288)])
 def test_weight_gradient_with_batchnorm_relu_applied_on_the_input(ops, case):
     """aau_conv_wgrad_bnin: same bits as aau_bn_act into a buffer followed by aau_conv_wgrad (deterministic split-K
     workspace), zero padding of the ACTIVATION at the border included."""

@@ -322,7 +322,7 @@ def test_default_on_fused_paths_against_their_off_switches_at_the_metric_shape(A
 
     la, ga, na = run()
     assert "aau_conv_igemm_bnred" in na and "aau_conv_igemm_multi" in na and "aau_poolbranch_fwd" in na
-    assert na.count("aau_conv_igemm_bnin") == 2 and na.count("aau_conv_wgrad_bnin") == 2      # d1.1 and u1.conv.1
+    assert na.count("aau_conv_igemm_bnin") == 4 and na.count("aau_conv_wgrad_bnin") == 4      # d1.1, d2.1, u2.conv.1, u1.conv.1
     monkeypatch.setenv(switch, "1")
     lb, gb, nb = run()
     assert "aau_bn_finalize_multi" in na and "aau_bn_bwd_apply_multi" in na
