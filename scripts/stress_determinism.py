@@ -120,4 +120,165 @@ def run_bnred(name, reps=12):
 
 tot += run_bnred("conv3x3s bnred 512 48->48")
 tot += run_case("conv1x1_resw 256 96->48", 8, 256, 256, 96, 48, 1, 1, reps=12)
+
+
+# ---- round 4: the MFMA kernels the screen did not cover yet ------------------------------------------
+def run_acc(name, N, H, W, Ci, Co, k, reps=12, shuffle=0):
+    """a conv that ADDS into its destination (read-modify-write epilogues): every repetition starts from the same contents"""
+    x = torch.randn(N, H, W, Ci, device="cuda").to(torch.bfloat16)
+    cp = ops.cpad_of(Ci)
+    w = (torch.randn(Co, k * k, cp, device="cuda") / (Ci * k * k) ** 0.5).to(torch.bfloat16)
+    if cp != Ci: w[:, :, Ci:] = 0
+    if shuffle:
+        d = ops.conv_desc(N, H, W, Ci, Ci, H, W, Co, Co // 4, Cpad=cp, shuffle2x2=1)
+        base = torch.full((N * 4 * H * W, Co // 4), float("nan"), dtype=torch.bfloat16, device="cuda")
+    else:
+        d = ops.conv_desc(N, H, W, Ci, Ci, H, W, Co, Co, k, k, 1, k // 2, 1, cp, accumulate=1)
+        base = torch.randn(N * H * W, Co, device="cuda").to(torch.bfloat16)
+    other = torch.randn(64 << 20, device="cuda")
+    outs = []
+    for r in range(reps):
+        out = base.clone()
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_igemm(d, x, w, out)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(out)
+    torch.cuda.synchronize()
+    bad = sum(0 if torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) else 1 for o in outs[1:])
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0].float()).sum())}", flush=True)
+    return bad
+
+
+tot += run_acc("conv3x3p dgrad accumulate 128 192->384", 8, 128, 128, 192, 384, 3)
+tot += run_acc("conv3x3p dgrad accumulate 64 384->768", 8, 64, 64, 384, 768, 3)
+tot += run_acc("conv1x1_rs accumulate 256 48->96", 8, 256, 256, 48, 96, 1)
+tot += run_acc("conv1x1_rs accumulate 128 96->192", 8, 128, 128, 96, 192, 1)
+tot += run_acc("conv1x1_rs ConvT 256 96->4x48", 8, 256, 256, 96, 192, 1, shuffle=1)
+tot += run_acc("conv1x1_rs ConvT 128 192->4x96", 8, 128, 128, 192, 384, 1, shuffle=1)
+
+
+def run_bnin(name, N, H, W, Ci, Co, reps=12):
+    """strip conv and 3x3 weight gradient with BatchNorm + ReLU applied on the operand in LDS (own-piece rewrites behind
+    counted vmcnt waits)"""
+    z = (torch.randn(N, H, W, Ci, device="cuda") * 1.5).to(torch.bfloat16)
+    dz = torch.randn(N, H, W, Co, device="cuda").to(torch.bfloat16)
+    cp = ops.cpad_of(Ci)
+    w = (torch.randn(Co, 9, cp, device="cuda") / (Ci * 9) ** 0.5).to(torch.bfloat16)
+    if cp != Ci: w[:, :, Ci:] = 0
+    sc, sh = torch.randn(Ci, device="cuda"), torch.randn(Ci, device="cuda") * 0.5 + 0.4
+    df = ops.conv_desc(N, H, W, Ci, Ci, H, W, Co, Co, 3, 3, 1, 1, 1, cp)
+    dw_ = ops.conv_desc(N, H, W, Ci, Ci, H, W, Co, Co, 3, 3, 1, 1, 1)
+    assert ops.conv_bnin_ok(df) and ops.conv_wgrad_bnin_ok(dw_)
+    ws = torch.full((ops.conv_wgrad_ws_bytes(dw_) // 4,), float("nan"), device="cuda")
+    other = torch.randn(64 << 20, device="cuda")
+    outs, dws, sts = [], [], []
+    for r in range(reps):
+        out = torch.full((N * H * W, Co), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dw = torch.zeros(Co, 9, Ci, device="cuda")
+        st = ops.stats_buffer(Co)
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_igemm_bnin(df, z, sc, sh, w, out, st)
+        ops.conv_wgrad_bnin(dw_, z, sc, sh, dz, dw, ws)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(out); dws.append(dw); sts.append(ops.stats_totals(st, Co))
+    torch.cuda.synchronize()
+    bad = sum(0 if (torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) and torch.equal(g, dws[0]) and torch.equal(t, sts[0]))
+              else 1 for o, g, t in zip(outs[1:], dws[1:], sts[1:]))
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0].float()).sum())}", flush=True)
+    return bad
+
+
+tot += run_bnin("bnin conv3x3s + wgrad3x3 512 48->48", 8, 512, 512, 48, 48)
+tot += run_bnin("bnin conv3x3s + wgrad3x3r 256 96->96", 8, 256, 256, 96, 96)
+
+
+def run_wgrad_group(name, reps=12):
+    """grouped bridge weight gradient (wgradL_pp: per-XCD work queues, ping-pong groups, ordered read-modify-write of dw)"""
+    B, H, Ci, Co = 8, 32, 768, 384
+    segs = [(1, 1), (3, 6), (3, 12), (3, 18)]
+    descs, srcs, dzs = [], [], []
+    x = torch.randn(B, H, H, Ci, device="cuda").to(torch.bfloat16)
+    for k, dil in segs:
+        srcs.append(x)
+        dzs.append(torch.randn(B, H, H, Co, device="cuda").to(torch.bfloat16))
+        descs.append(ops.conv_desc(B, H, H, Ci, Ci, H, H, Co, Co, k, k, 1, dil * (k // 2), dil))
+    assert ops.conv_wgrad_group_ok(descs)
+    other = torch.randn(64 << 20, device="cuda")
+    outs = []
+    for r in range(reps):
+        dws = [torch.zeros(Co, k * k, Ci, device="cuda") for k, _ in segs]
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_wgrad_group(descs, srcs, dzs, dws)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(torch.cat([t.flatten() for t in dws]))
+    torch.cuda.synchronize()
+    bad = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0]).sum())}", flush=True)
+    return bad
+
+
+tot += run_wgrad_group("wgradL grouped bridge wgrad")
+
+
+def run_multi(name, reps=20):
+    """the four spatial ASPP branches as one launch (igemm_multi), outputs and statistics"""
+    B, H, Ci, Co = 8, 32, 384, 768
+    segs = [(1, 1), (3, 6), (3, 12), (3, 18)]
+    x = torch.randn(B, H, H, Ci, device="cuda").to(torch.bfloat16)
+    descs, wpks = [], []
+    for k, dil in segs:
+        wpks.append((torch.randn(Co, k * k, Ci, device="cuda") / (Ci * k * k) ** 0.5).to(torch.bfloat16))
+        descs.append(ops.conv_desc(B, H, H, Ci, Ci, H, H, Co, Co, k, k, 1, dil * (k // 2), dil, Ci))
+    assert ops.conv_igemm_multi_ok(descs)
+    other = torch.randn(64 << 20, device="cuda")
+    outs, sts = [], []
+    for r in range(reps):
+        dsts = [torch.full((B * H * H, Co), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in segs]
+        st = [ops.stats_buffer(Co) for _ in segs]
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_igemm_multi(descs, [x] * 4, wpks, dsts, st)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(torch.cat([t.flatten() for t in dsts])); sts.append(torch.cat([ops.stats_totals(t, Co).flatten() for t in st]))
+    torch.cuda.synchronize()
+    bad = sum(0 if (torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) and torch.equal(t, sts[0])) else 1
+              for o, t in zip(outs[1:], sts[1:]))
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0].float()).sum())}", flush=True)
+    return bad
+
+
+tot += run_multi("igemm_multi ASPP branches")
+
+
+def run_poolbranch(name, reps=20):
+    """image-pool branch kernels (one wave per channel, batch statistics in registers)"""
+    B, Ci, Co = 8, 384, 768
+    g = torch.randn(B, Ci, device="cuda").to(torch.bfloat16)
+    cp = ops.cpad_of(Ci)
+    w = (torch.randn(Co, 1, cp, device="cuda") / Ci ** 0.5).to(torch.bfloat16)
+    gam, bet = torch.rand(Co, device="cuda") + 0.5, torch.randn(Co, device="cuda") * 0.1
+    dy = torch.randn(B, Co, device="cuda").to(torch.bfloat16)
+    cpd = ops.cpad_of(Co)
+    wd = (torch.randn(Ci, 1, cpd, device="cuda") / Co ** 0.5).to(torch.bfloat16)
+    other = torch.randn(64 << 20, device="cuda")
+    outs = []
+    for r in range(reps):
+        z = torch.empty(B, Co, dtype=torch.bfloat16, device="cuda")
+        rm, rv, nbt = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+        sc, sh, mu, istd = (torch.empty(Co, device="cuda") for _ in range(4))
+        dz = torch.empty(B, Co, dtype=torch.bfloat16, device="cuda")
+        dga, dbe, dw = torch.zeros(Co, device="cuda"), torch.zeros(Co, device="cuda"), torch.zeros(Co, 1, Ci, device="cuda")
+        dx = torch.empty(B, Ci, dtype=torch.bfloat16, device="cuda")
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.poolbranch_fwd(g, Ci, w, cp, z, gam, bet, rm, rv, nbt, sc, sh, mu, istd, B, Ci, Co)
+        ops.poolbranch_bwd(dy, Co, z, g, Ci, gam, sc, sh, mu, istd, dz, dga, dbe, dw, B, Ci, Co)
+        ops.poolbranch_dx(dz, wd, cpd, dx, Ci, B, Ci, Co)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(torch.cat([z.float().flatten(), sc, sh, dz.float().flatten(), dga, dbe, dw.flatten(), dx.float().flatten()]))
+    torch.cuda.synchronize()
+    bad = sum(0 if torch.equal(o, outs[0]) else 1 for o in outs[1:])
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0]).sum())}", flush=True)
+    return bad
+
+
+tot += run_poolbranch("poolbranch fwd / bwd / dx")
 print("TOTAL mismatches", tot)
