@@ -147,12 +147,15 @@ def test_trained_step_gradients_match_reference(A, golden):
         rows.append((rel(e, r), float((e - r).norm() / (r.norm() + 1e-30)), float((e - r).norm() / G), float(r.norm() / G), k))
     errs = sorted(r[0] for r in rows)
     med, p90, worst = errs[len(errs) // 2], errs[int(len(errs) * 0.9)], max(rows)
-    assert med < 0.03, (med, p90, worst)
-    assert p90 < 0.09, (med, p90, worst)
-    assert worst[0] < 0.5, worst
-    # what sits above 10 % must be a near-cancelling sum that carries next to nothing of the gradient (table: < 0.05 %)
+    # measured (round 4): median 1.7 %, 90th percentile 6.4 %, worst 31.7 % (u3.att.psi.1.bias)
+    assert med < 0.025, (med, p90, worst)
+    assert p90 < 0.08, (med, p90, worst)
+    assert worst[0] < 0.45, worst
+    # what sits above 10 % must be one of the six near-cancelling sums named above, carrying next to nothing of the gradient
     loud = [r for r in rows if r[0] > 0.10]
-    assert len(loud) <= 8 and all(r[3] < 2e-3 for r in loud), loud
+    known = {"u3.att.psi.1.bias", "bridge.project.1.bias", "d4.0.block.1.bias", "bridge.project.0.weight",
+             "d4.1.block.0.weight", "bridge.blocks.2.0.weight"}
+    assert {r[4] for r in loud} <= known and all(r[3] < 2e-3 for r in loud), loud
     heavy = [r for r in rows if r[3] >= 1e-3]                # the tensors that carry 99.99 % of the gradient
     assert len(heavy) >= 30 and max(r[1] for r in heavy) < 0.07, sorted(heavy, key=lambda r: -r[1])[:3]
     assert max(r[2] for r in rows) < 5e-3, sorted(rows, key=lambda r: -r[2])[:3]
@@ -259,11 +262,12 @@ def test_other_shapes_and_rates_against_emulated_oracle(A, cfg):
         lo = ref(x)
         le = m(x.cuda())
     # train mode with tiny batches is the noisiest setting (batch statistics over 2-3 frames)
-    assert rel(le, lo) < 8e-2
-    assert float((le.cpu() - lo).abs().mean() / lo.abs().max()) < 1e-2
+    # (measured, round 4: max 4.1-4.3 %, mean 0.49-0.55 % over the three configurations; eval 0.03-0.24 %)
+    assert rel(le, lo) < 6e-2
+    assert float((le.cpu() - lo).abs().mean() / lo.abs().max()) < 8e-3
     ref.eval(); m.eval()
     with torch.no_grad():
-        assert rel(m(x.cuda()), ref(x)) < 3e-2
+        assert rel(m(x.cuda()), ref(x)) < 8e-3
 
 
 def test_benchmark_configuration_step_matches_oracle(A):
