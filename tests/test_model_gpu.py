@@ -379,6 +379,35 @@ def test_realistic_width_dice_within_1e3_of_reference(A, golden):
     assert float(np.mean((tta > 0.5) != (g["tta_prob0"].astype(np.float32) > 0.5))) < 1e-3
 
 
+def test_metric_width_dice_within_1e3_of_reference(A, golden):
+    """base_c 48, 1x512x512 (the benchmark configuration) with reference-trained weights (oracle/make_golden_c48.py): the
+    BASELINE.json bar |Dice_build - Dice_ref| <= 1e-3 at the metric width, for evaluate() (pipeline:235-241) and for the
+    integer-count Dice / IoU of eval_segmentation_batch.py:41-49 on the thresholded masks."""
+    g = golden("g9_trained_c48_512.npz")
+    sd = {}
+    for k, v in g.items():
+        if k.startswith("sd_bf16/"):
+            sd[k[8:]] = torch.from_numpy(v.copy()).view(torch.bfloat16).float()
+        elif k.startswith("sd_raw/"):
+            sd[k[7:]] = torch.from_numpy(v.copy())
+    m = A.AttentionASPPUNet(base_c=48)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).float().cuda()
+    with torch.no_grad():
+        l = m(x)
+    ref_l = torch.from_numpy(g["eval_logits"].astype(np.float32))
+    assert rel(l, ref_l) < 2e-2, rel(l, ref_l)
+    d, i = A.evaluate(m, [(x[:2], y[:2]), (x[2:], y[2:])], torch.device("cuda"))
+    assert abs(d - float(g["evaluate_dice"])) < 1e-3 and abs(i - float(g["evaluate_iou"])) < 1e-3, (d, i)
+    masks = (torch.sigmoid(l) > 0.5).to(torch.uint8)[:, 0]
+    gts = (y[:, 0] > 0).to(torch.uint8)
+    for k in range(4):
+        assert abs(A.evalseg.dice(masks[k], gts[k]) - float(g["seg_dice"][k])) < 1e-3, k
+        assert abs(A.evalseg.iou(masks[k], gts[k]) - float(g["seg_iou"][k])) < 2e-3, k
+        assert abs(int(masks[k].sum()) - int(g["mask_counts"][k])) <= max(8, 0.002 * int(g["mask_counts"][k])), k
+
+
 def test_realistic_width_train_step_matches_reference(A, golden):
     m, g = _g7_model(A, golden)
     m.train()

@@ -126,6 +126,25 @@ def test_realistic_width_fixture_pins_oracle(golden):
     assert abs(d - float(g["evaluate_dice"])) < 1e-5 and abs(i - float(g["evaluate_iou"])) < 1e-5
 
 
+def test_metric_width_fixture_pins_oracle(golden):
+    """base_c 48 / 512x512 -- the configuration bench.py measures -- with weights the reference trained briefly on synthetic
+    phantoms (oracle/make_golden_c48.py): eval logits and evaluate() from the restatement on the stored weights."""
+    g = golden("g9_trained_c48_512.npz")
+    sd = {k[8:]: torch.from_numpy(v.copy()).view(torch.bfloat16).float() for k, v in g.items() if k.startswith("sd_bf16/")}
+    sd.update({k[7:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("sd_raw/")})
+    net = O.AttentionASPPUNet(base_c=48)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"]).float()
+    with torch.no_grad():
+        lv = net(x[:2])
+    ref = g["eval_logits"][:2].astype(np.float32)
+    assert np.abs(lv.numpy() - ref).max() < 2e-3 * np.abs(ref).max() + 1e-3       # fixture logits are stored as fp16
+    assert float(g["undecided_share"]) < 0.01 and g["seg_dice"].min() > 0.9        # decisive masks
+    d, i = O.evaluate(net, [(x[:2], y[:2]), (x[2:], y[2:])], torch.device("cpu"))
+    assert abs(d - float(g["evaluate_dice"])) < 1e-5 and abs(i - float(g["evaluate_iou"])) < 1e-5
+
+
 def test_legacy_key_rename():
     sd = {"u4.att.W_g.0.weight": 1, "u4.att.W_x.1.bias": 2, "d1.0.block.0.weight": 3}
     out = O.rename_legacy_keys(sd)
