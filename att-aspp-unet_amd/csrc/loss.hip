@@ -15,7 +15,8 @@ namespace aau {
 
 // sums layout per sample: 0 sum t, 1 sum p, 2 sum p*t, 3 sum bce, 4 sum |gp-gt|, 5 sum pbin, 6 sum pbin*t
 constexpr int NS = 8;
-constexpr int TILE = 16;
+constexpr int TILE = 32;                 // pixels per workgroup side: 256 threads x PPT pixels (a 16 x 16 tile per workgroup was
+constexpr int PPT = TILE * TILE / 256;   // 8192 latency-bound workgroups with 15 barriers each: 33 + 26 us per step)
 constexpr int NREP = AAU_STAT_REPLICAS;  // sums workspace = fp32 [NREP][B][NS] (the ABI's size)
 // Inside that workspace: the first [B][NS] floats are the per-sample table the consumers read; behind it live
 // NACC replicas of int64 [B][NS] fixed-point accumulators (value * 2^32; tile sums stay below 2^30) and a poison word.
@@ -32,20 +33,27 @@ __device__ __forceinline__ float bce_elem(float x, float t) {
     return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
 }
 
-__device__ __forceinline__ float block_sum(float v, float* s4) {
+// seven sums at once: wave shuffles, one LDS exchange, thread k < 7 returns total k (the others 0)
+__device__ __forceinline__ float block_sum7(float (&v)[7], float (*s74)[4]) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s74[k][threadIdx.x >> 6] = v[k];
+    }
     __syncthreads();
-    return s4[0] + s4[1] + s4[2] + s4[3];
+    return threadIdx.x < 7 ? s74[threadIdx.x][0] + s74[threadIdx.x][1] + s74[threadIdx.x][2] + s74[threadIdx.x][3] : 0.f;
 }
 
-// grid: (tiles_x, tiles_y, B); block 16x16
+// grid: (tiles_x, tiles_y, B); 256 threads, PPT pixels each
 __global__ __launch_bounds__(256) void crit_reduce_kernel(const float* logits, const float* targets, float* sums,
                                                           int H, int W, float thr_logit, int with_edge) {
     __shared__ float sp[TILE + 2][TILE + 2], st[TILE + 2][TILE + 2];
-    __shared__ float s4[4];
+    __shared__ float s74[7][4];
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
     const float* L = logits + (int64_t)b * H * W;
@@ -59,15 +67,17 @@ __global__ __launch_bounds__(256) void crit_reduce_kernel(const float* logits, c
         st[ly][lx] = in ? Tt[(int64_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    const int ly = tid / TILE, lx = tid % TILE;
-    const int y = y0 + ly, x = x0 + lx;
     float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (y < H && x < W) {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int ly = (tid + k * 256) / TILE, lx = (tid + k * 256) % TILE;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
         const float l = L[(int64_t)y * W + x];
         const float p = sp[ly + 1][lx + 1], t = st[ly + 1][lx + 1];
-        v[0] = t; v[1] = p; v[2] = p * t; v[3] = bce_elem(l, t);
+        v[0] += t; v[1] += p; v[2] += p * t; v[3] += bce_elem(l, t);
         const float pb = l > thr_logit ? 1.f : 0.f;
-        v[5] = pb; v[6] = pb * t;
+        v[5] += pb; v[6] += pb * t;
         if (with_edge) {
 #define SOBEL(A, gx, gy)                                                                              \
     const float gx = (A[ly][lx] - A[ly][lx + 2]) + 2.f * (A[ly + 1][lx] - A[ly + 1][lx + 2]) +        \
@@ -76,20 +86,17 @@ __global__ __launch_bounds__(256) void crit_reduce_kernel(const float* logits, c
                      (A[ly + 2][lx] + 2.f * A[ly + 2][lx + 1] + A[ly + 2][lx + 2]);
             SOBEL(sp, gxp, gyp)
             SOBEL(st, gxt, gyt)
-            v[4] = fabsf(sqrtf(gxp * gxp + gyp * gyp + 1e-8f) - sqrtf(gxt * gxt + gyt * gyt + 1e-8f));
+            v[4] += fabsf(sqrtf(gxp * gxp + gyp * gyp + 1e-8f) - sqrtf(gxt * gxt + gyt * gyt + 1e-8f));
         }
     }
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const float s = block_sum(v[k], s4);
-        if (tid == 0 && s != 0.f) {
-            unsigned long long* acc = crit_acc(sums, (int)gridDim.z);
-            if (!(fabsf(s) < 1.0e9f)) {
-                atomicOr(acc + (size_t)NACC * gridDim.z * NS, 1ull);                  // poison
-            } else {
-                const long long q = (long long)rint((double)s * 4294967296.0);
-                atomicAdd(acc + ((size_t)((blockIdx.x + blockIdx.y) % NACC) * gridDim.z + b) * NS + k, (unsigned long long)q);
-            }
+    const float s = block_sum7(v, s74);
+    if (tid < 7 && s != 0.f) {
+        unsigned long long* acc = crit_acc(sums, (int)gridDim.z);
+        if (!(fabsf(s) < 1.0e9f)) {
+            atomicOr(acc + (size_t)NACC * gridDim.z * NS, 1ull);                  // poison
+        } else {
+            const long long q = (long long)rint((double)s * 4294967296.0);
+            atomicAdd(acc + ((size_t)((blockIdx.x + blockIdx.y) % NACC) * gridDim.z + b) * NS + tid, (unsigned long long)q);
         }
     }
 }
@@ -192,9 +199,11 @@ __global__ __launch_bounds__(256) void crit_grad_kernel(const float* logits, con
         }
         __syncthreads();
     }
-    const int ly = tid / TILE, lx = tid % TILE;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+    const int ly = (tid + k * 256) / TILE, lx = (tid + k * 256) % TILE;
     const int y = y0 + ly, x = x0 + lx;
-    if (y >= H || x >= W) return;
+    if (y >= H || x >= W) continue;
     const float l = L[(int64_t)y * W + x], t = Tt[(int64_t)y * W + x];
     const float p = sigmoidf_(l);
     const float w = (finetune && !pos) ? neg_w : 1.f;
@@ -214,6 +223,7 @@ __global__ __launch_bounds__(256) void crit_grad_kernel(const float* logits, con
         }
     }
     dlogits[(int64_t)b * H * W + (int64_t)y * W + x] = g * loss_scale;
+    }
 }
 
 // ---- the loss classes used on their own (pipeline:173-189 DiceLoss / TverskyLoss / ComboLoss, :196-216 EdgeLoss) ----
@@ -282,9 +292,11 @@ __global__ __launch_bounds__(256) void terms_grad_kernel(const float* logits, co
         }
         __syncthreads();
     }
-    const int ly = tid / TILE, lx = tid % TILE;
+#pragma unroll
+    for (int kk = 0; kk < PPT; ++kk) {
+    const int ly = (tid + kk * 256) / TILE, lx = (tid + kk * 256) % TILE;
     const int y = y0 + ly, x = x0 + lx;
-    if (y >= H || x >= W) return;
+    if (y >= H || x >= W) continue;
     const float l = L[(int64_t)y * W + x], t = Tt[(int64_t)y * W + x];
     const float p = sigmoidf_(l);
     float g = k.w_bce * inv_all * (p - t);
@@ -300,6 +312,7 @@ __global__ __launch_bounds__(256) void terms_grad_kernel(const float* logits, co
         g += k.w_edge * inv_all * (ax + ay) * p * (1.f - p);
     }
     dlogits[(int64_t)b * H * W + (int64_t)y * W + x] = g;
+    }
 }
 
 __global__ void seg_metrics_kernel(const float* sums, float* out, int B) {

@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256) void outconv_bwd_kernel(const unsigned short* 
 #pragma unroll
         for (int j = 0; j < 8; ++j) wv[j] = w[c + j];
         const int64_t m0 = slice_begin(ppb), m1 = min(M, m0 + ppb);
-        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {
+#pragma unroll 2
+        for (int64_t m = m0 + pl; m < m1; m += mp.PL) {      // two pixels' loads in flight per thread
             const float g = dl[m];
             float f[8], o[8];
             unpack8(*(const u32x4*)(y + m * yp + c), f);
