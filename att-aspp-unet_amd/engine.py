@@ -406,6 +406,8 @@ class Plan:
         ReLU applied on the operand -- in the forward conv AND in the weight gradient (both must be served)?"""
         if not self.train or self.eng.no_bnin:
             return False
+        if Cprev > self.eng.bnin_max_c:
+            return False
         cv = self.eng.store.convs[cname]
         if cv.kind != "conv" or cv.k != 3 or cv.dil != 1 or cv.I != Cprev:
             return False
@@ -1086,6 +1088,7 @@ class Engine:
         self.no_fuse_bnred = os.environ.get("AAU_NO_BNRED", "0") == "1"
         self.no_bnin = os.environ.get("AAU_NO_BNIN", "0") == "1"     # A/B: ConvBNReLU pairs with the activation in memory
         self.no_bn_multi = os.environ.get("AAU_NO_BN_MULTI", "0") == "1"   # A/B: one BatchNorm launch per ASPP branch
+        self.bnin_max_c = int(os.environ.get("AAU_BNIN_MAX_C", "96"))     # A/B: widest producing layer whose BN + ReLU moves onto the operand
         # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
         # reading the routed gradient the reduce pass stored
         self.pool_store_routed = os.environ.get("AAU_POOL_APPLY_ROUTES", "0") != "1"
