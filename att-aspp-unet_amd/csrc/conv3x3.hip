@@ -2562,7 +2562,6 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     int gx = 256 * per_cu / ntq;
     if (gx > npatch) gx = npatch;
     if (gx < 1) gx = 1;
-    prof_tag(BQ == 48 ? "conv1x1_resw<48>" : "conv1x1_resw<96>");
     auto go = [&](auto kern) {
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
@@ -2573,6 +2572,7 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     const int64_t Mo = (int64_t)d->N * d->H * d->W * (d->shuffle2x2 ? 4 : 1);
     const bool wide_ok = ((uintptr_t)dst & 15) == 0 && d->dst_pitch % 8 == 0 && (!d->shuffle2x2 || (d->Cout >> 2) % 8 == 0) && !a.nowide;
     const bool rs = nbuf == 7 && wide_ok && a.nchunk <= 6 && Mo * d->dst_pitch * 2 < 0x7fffffff && !getenv("AAU_PW_OLD");
+    prof_tag(rs ? (BQ == 48 ? "conv1x1_rs<48>" : "conv1x1_rs<96>") : (BQ == 48 ? "conv1x1_resw<48>" : "conv1x1_resw<96>"));
     if (BQ == 48) {
         if (rs) { if (d->accumulate) go(conv1x1_rs_kernel<48, 8, true>); else go(conv1x1_rs_kernel<48, 8, false>); }
         else if (nbuf == 7) go(conv1x1_resw_kernel<48, 8, 7>);
