@@ -94,28 +94,34 @@ for name, hi, gc, Co in UPS:
     Mi, Mo = B * hi * hi, B * ho * ho
     gf = 2.0 * Mi * gc * 4 * Co / 1e9
     g = torch.randn(Mi, gc, device="cuda").to(torch.bfloat16)
-    cat = torch.randn(Mo, 2 * Co, device="cuda").to(torch.bfloat16)
+    # level 1 keeps the concatenation as two dense planes (engine.py: the strip kernels read a two-plane source), the deeper
+    # levels interleave skip | up in one buffer of pitch 2 Co
+    planar = name == "u1.up"
+    cp2 = Co if planar else 2 * Co                      # pitch of the buffer the up half lives in
+    catbuf = torch.randn(Mo, cp2, device="cuda").to(torch.bfloat16)
+    cat = catbuf if planar else None
+    up = catbuf if planar else catbuf[:, Co:]
     line = f"{name:8s} {gf:7.1f} GF"
     if "fwd" in tot:
         cp = ops.cpad_of(gc)
         w = (torch.randn(4 * Co, 1, cp, device="cuda") / gc ** 0.5).to(torch.bfloat16)
         bias = torch.zeros(Co, device="cuda")
-        d = ops.conv_desc(B, hi, hi, gc, gc, hi, hi, 4 * Co, 2 * Co, Cpad=cp, shuffle2x2=1)
-        t = timeit(lambda: ops.conv_igemm(d, g, w, cat[:, Co:], bias=bias))
+        d = ops.conv_desc(B, hi, hi, gc, gc, hi, hi, 4 * Co, cp2, Cpad=cp, shuffle2x2=1)
+        t = timeit(lambda: ops.conv_igemm(d, g, w, up, bias=bias))
         tot["fwd"] += t
         line += f" | fwd {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     if "dgrad" in tot:
         cp = ops.cpad_of(Co)
         w = (torch.randn(gc, 4, cp, device="cuda") / (4 * Co) ** 0.5).to(torch.bfloat16)
         out = torch.empty(Mi, gc, device="cuda", dtype=torch.bfloat16)
-        d = ops.conv_desc(B, ho, ho, Co, 2 * Co, hi, hi, gc, gc, 2, 2, 2, 0, 1, cp)
-        t = timeit(lambda: ops.conv_igemm(d, cat[:, Co:], w, out))
+        d = ops.conv_desc(B, ho, ho, Co, cp2, hi, hi, gc, gc, 2, 2, 2, 0, 1, cp)
+        t = timeit(lambda: ops.conv_igemm(d, up, w, out))
         tot["dgrad"] += t
         line += f" | dgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     if "wgrad" in tot:
         dw = torch.zeros(gc, 4, Co, device="cuda")
-        d = ops.conv_desc(B, ho, ho, Co, 2 * Co, hi, hi, gc, gc, 2, 2, 2, 0, 1)
-        t = timeit(lambda: wgrad(d, cat[:, Co:], g, dw))
+        d = ops.conv_desc(B, ho, ho, Co, cp2, hi, hi, gc, gc, 2, 2, 2, 0, 1)
+        t = timeit(lambda: wgrad(d, up, g, dw))
         tot["wgrad"] += t
         line += f" | wgrad {t:7.1f} us {gf / t * 1e3:6.0f} TF"
     print(line, flush=True)
