@@ -643,3 +643,24 @@ def test_multi_layer_batchnorm_launches_equal_the_single_layer_ones(ops):
         assert float((a["dbet"][i] - b["dbet"][i]).abs().max()) <= 1e-5 * float(a["dbet"][i].abs().max()) + 1e-6
     # with the single-layer sums handed to the multi apply the gradients are the same bits
     assert int(b["nbt"][0]) == 1
+
+
+def test_zero_multi_clears_buffers_and_bumps_the_counter(ops):
+    """aau_zero_multi: any number of buffers (groups of eight per launch), the 64-bit counter bumped once, mod 2^64."""
+    from att_aspp_unet_amd import _abi
+    bufs = [torch.full((4 * (i + 1) * 13,), float(i + 1), device="cuda") for i in range(11)]
+    bufs.append(torch.full((6,), 7, dtype=torch.int64, device="cuda"))           # 48 bytes
+    guard = torch.full((64,), 3.0, device="cuda")
+    cnt = torch.tensor([-5], dtype=torch.int64, device="cuda")
+    ops.zero_multi(bufs, cnt, 0x9E3779B97F4A7C15)
+    torch.cuda.synchronize()
+    assert all(int((b != 0).sum()) == 0 for b in bufs) and bool((guard == 3.0).all())
+    assert int(cnt) == ((-5 + 0x9E3779B97F4A7C15) + (1 << 63)) % (1 << 64) - (1 << 63)
+    ops.zero_multi([], cnt, 5)                                               # counter only
+    torch.cuda.synchronize()
+    assert int(cnt) == ((0x9E3779B97F4A7C15) + (1 << 63)) % (1 << 64) - (1 << 63)
+    odd = torch.ones(9, device="cuda")                                        # 36 bytes: not a multiple of 16
+    with pytest.raises(_abi.AauError):
+        ops.zero_multi([odd])
+    with pytest.raises(_abi.AauError):
+        ops.zero_multi([torch.ones(16, device="cuda")[1:13]])                # misaligned start

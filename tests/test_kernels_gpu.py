@@ -937,3 +937,49 @@ def test_igemm_multi_equals_the_separate_launches(ops):
     # a problem the wide tile does not serve is refused
     small = ops.conv_desc(1, 16, 16, 64, 64, 16, 16, 96, 96, 1, 1, 1, 0, 1, 64)
     assert not ops.conv_igemm_multi_ok([descs[0], small])
+
+
+@pytest.mark.parametrize("case", [(4, 256, 256, 96, 48, 0, 0), (4, 256, 256, 40, 104, 0, 1), (4, 256, 256, 48, 96, 0, 1),
+                                  (5, 256, 240, 192, 96, 0, 0), (8, 128, 128, 192, 384, 1, 0), (4, 256, 256, 96, 192, 1, 0)])
+def test_round4_1x1_kernel_equals_the_ring_kernel_it_replaces(ops, case, monkeypatch):
+    """conv1x1_rs_kernel (scalar-offset fills and stores, prefetched read-modify-write with hand-counted waits) against
+    conv1x1_resw_kernel (AAU_PW_OLD=1) on the same operands: outputs bit for bit (statistics to fp32 rounding) -- plain, accumulating
+    (bias + affine + ReLU on top of an existing destination), pixel-shuffle stores, channel tails in both operands."""
+    N, H, W, Cin, Cout, shuffle, acc = case
+    g = torch.Generator().manual_seed(900 + sum(case))
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).cuda()
+    cp = ops.cpad_of(Cin)
+    w = torch.zeros(Cout, 1, cp)
+    w[:, 0, :Cin] = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
+    w = w.to(torch.bfloat16).cuda()
+    Co = Cout // 4 if shuffle else Cout
+    bias = torch.randn(Co, generator=g).cuda()
+    scale, shift = (torch.rand(Co, generator=g) + 0.5).cuda(), torch.randn(Co, generator=g).cuda()
+    prev = torch.randn(N * H * W * (4 if shuffle else 1), Co + 8, generator=g).to(torch.bfloat16).cuda()
+    if shuffle:
+        d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Co + 8, Cpad=cp, shuffle2x2=1)
+    else:
+        d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Co + 8, Cpad=cp, accumulate=acc, relu=acc)
+
+    def run():
+        out = prev.clone()
+        st = None if acc else ops.stats_buffer(Cout if not shuffle else Cout)
+        with launch_tags() as lt:
+            if acc:
+                ops.conv_igemm(d, x, w, out, bias=bias, scale=scale, shift=shift)
+            elif shuffle:
+                ops.conv_igemm(d, x, w, out, bias=bias)
+            else:
+                ops.conv_igemm(d, x, w, out, stats=st)
+        torch.cuda.synchronize()
+        return out, (None if st is None or shuffle else st.clone()), [t.split(" ")[0] for t in lt]
+
+    new, st_new, tag_new = run()
+    monkeypatch.setenv("AAU_PW_OLD", "1")
+    old, st_old, tag_old = run()
+    assert tag_new[0].startswith("conv1x1_rs<") and tag_old[0].startswith("conv1x1_resw<"), (tag_new, tag_old)
+    assert torch.equal(new.view(torch.int16), old.view(torch.int16))
+    assert float(new[:, Co:].float().abs().sum()) == float(prev[:, Co:].float().abs().sum())     # the pad columns are untouched
+    if st_new is not None:      # (the per-workgroup fp32 partial sums contract differently in the two instantiations: last bits)
+        a, b = ops.stats_totals(st_new, Cout), ops.stats_totals(st_old, Cout)
+        assert float(((a - b).abs() / (b.abs() + 1.0)).max()) < 1e-5
