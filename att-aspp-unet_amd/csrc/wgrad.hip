@@ -42,6 +42,8 @@ struct WgradArgs {
     int linear;         // 1: gather(m) == m (1x1, stride 1, pad 0)
     int rev;            // 1: workgroups take the split ranges from the end (aau_traverse)
     float* ws;          // split-K slabs [workgroup][9 acc tiles][256 threads][4] (null: fp32 atomics into dw)
+    unsigned src_bytes, dz_bytes;   // extents for the buffer descriptors of the fast issue path
+    int fast_ok;        // both tensors below 2 GiB (32-bit buffer offsets); AAU_WG_NOFAST=1 switches the path off (A/B)
 };
 
 // byte offset of (row, channel ch [multiple of 4]) in a [rows][48*TT] bf16 tile
@@ -136,7 +138,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         xx[i] = rem - xy[i] * d.Wo;
     }
 
+    // Fast issue path (round 4; the form of conv1x1_rs / wgradL): when every K-step of this workgroup is a whole run of BKP
+    // consecutive output pixels whose source pixels are equally spaced (1x1, or the 2x2 / stride-2 gather of a ConvTranspose
+    // gradient with BKP dividing the output row), the per-lane part of a piece's address is a constant of the workgroup --
+    // channel masks folded in as an out-of-range offset -- and the step travels in the SCALAR offset of the LDS-DMA: no
+    // 64-bit address arithmetic, predicates or row / column decode per piece and step (the general path below spends
+    // more issue cycles on those than the step's MFMAs take: these launches ran at 3-4 TB/s).
+    constexpr unsigned OOB = 0x80000000u;
+    const bool gather2 = !a.linear && d.KH == 2 && d.KW == 2 && d.stride == 2 && d.pad == 0 && d.dil == 1 && d.H == 2 * d.Ho &&
+                         d.W == 2 * d.Wo && d.Wo % BKP == 0;
+    const bool fast = a.fast_ok && (a.linear || gather2) && (me - mb) % BKP == 0 && mb % BKP == 0;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, a.src_bytes, 0x00020000);
+    unsigned vy[NLY], vx[NLX];
+#pragma unroll
+    for (int i = 0; i < NLY; ++i) vy[i] = q0 + ych[i] < d.Cout ? (unsigned)((yrow[i] * d.dst_pitch + q0 + ych[i]) * 2) : OOB;
+#pragma unroll
+    for (int i = 0; i < NLX; ++i)
+        vx[i] = c0 + xch[i] < d.Cin ? (unsigned)(((a.linear ? xrow[i] : 2 * xrow[i]) * d.src_pitch + c0 + xch[i]) * 2) : OOB;
+    auto stage_fast = [&](int buf, int mbase) {
+        const unsigned sy = (unsigned)mbase * (unsigned)(d.dst_pitch * 2);
+        unsigned sx;
+        if (a.linear) {
+            sx = (unsigned)mbase * (unsigned)(d.src_pitch * 2);
+        } else {
+            const unsigned xo = (unsigned)mbase % (unsigned)d.Wo, t = (unsigned)mbase / (unsigned)d.Wo;
+            const unsigned yo = t % (unsigned)d.Ho, n = t / (unsigned)d.Ho;
+            sx = (unsigned)(((n * d.H + 2 * yo + dy) * d.W + 2 * xo + dx) * d.src_pitch * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < NLY; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LDS_PTR(sY(buf) + (256 * i + wave * 64) * 16), 16, (int)vy[i], (int)sy, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NLX; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(sX(buf) + (256 * i + wave * 64) * 16), 16, (int)vx[i], (int)sx, 0, 0);
+    };
     auto stage = [&](int buf, int mbase) {
+        if (fast) { stage_fast(buf, mbase); return; }
 #pragma unroll
         for (int i = 0; i < NLY; ++i) {
             const int m = mbase + yrow[i];
@@ -162,7 +200,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
     };
     auto advance = [&]() {
-        if (a.linear) return;
+        if (a.linear || fast) return;
 #pragma unroll
         for (int i = 0; i < NLX; ++i) {
             xx[i] += BKP;
@@ -465,6 +503,13 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
     a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
     a.M = d->N * d->Ho * d->Wo;
     a.linear = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo);
+    {
+        const int64_t sbytes = (((int64_t)d->N * d->H * d->W - 1) * d->src_pitch + d->Cin) * 2;
+        const int64_t zbytes = (((int64_t)a.M - 1) * d->dst_pitch + d->Cout) * 2;
+        a.fast_ok = sbytes < 0x7fffffff && zbytes < 0x7fffffff && !getenv("AAU_WG_NOFAST");
+        a.src_bytes = (unsigned)(a.fast_ok ? sbytes : 0);
+        a.dz_bytes = (unsigned)(a.fast_ok ? zbytes : 0);
+    }
     const bool split = d->src_split_c > 0 || d->dst_split_c > 0;
     if (split) {
         AAU_REQUIRE(wgrad3x3_applicable(d) && d->dst_split_c <= 0, "aau_conv_wgrad: a two-plane source is only served by the all-taps 3x3 kernel (aau_conv_split_ok)");
