@@ -47,7 +47,7 @@ U64 = C.c_uint64
 
 # entry points that take an aau_stat buffer: index of the pointer argument; its size in bytes is the NEXT argument
 # (include/aau.h: the library itself refuses an undersized buffer)
-STAT_ARG = {"aau_conv_igemm_bnin": 6, "aau_conv_igemm_bnred": 10, "aau_stats_to_red": 0, "aau_conv_igemm": 7, "aau_conv1_fwd": 3, "aau_bn_finalize": 0, "aau_gate_psi": 8, "aau_fold_stats": 0,
+STAT_ARG = {"aau_conv_igemm_bnin": 7, "aau_conv_igemm_bnred": 10, "aau_stats_to_red": 0, "aau_conv_igemm": 7, "aau_conv1_fwd": 3, "aau_bn_finalize": 0, "aau_gate_psi": 8, "aau_fold_stats": 0,
             "aau_stats_to_f64": 0}
 
 # name -> argtypes (all return int unless noted)
@@ -68,7 +68,9 @@ _SIGS = {
     "aau_conv_bnin_ok": [C.POINTER(ConvDesc)],
     "aau_conv_wgrad_bnin_ok": [C.POINTER(ConvDesc)],
     "aau_conv_wgrad_bnin": [C.POINTER(ConvDesc), P, P, P, P, P, P, L, P],
-    "aau_conv_igemm_bnin": [C.POINTER(ConvDesc), P, P, P, P, P, P, L, P],
+    "aau_conv_igemm_bnin": [C.POINTER(ConvDesc), P, P, P, P, P, P, P, L, P],
+    "aau_conv_wgrad_bnin_dz_ok": [C.POINTER(ConvDesc)],
+    "aau_conv_wgrad_bnin_dz": [C.POINTER(ConvDesc), P, P, P, P, P, P, L, P],
     "aau_traverse": [I],
     "aau_conv_wgrad": [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P],
     "aau_conv_split_ok": [C.POINTER(ConvDesc), I],

@@ -2303,6 +2303,22 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_rs_kernel(const C3Args a, int
         }
         __syncthreads();
     }
+    // BNIN (aau_conv_igemm_bnin on a 1x1 / ConvTranspose forward): the source is the raw conv output z of the producing
+    // ConvBNReLU; relu(z * scale + shift) is applied to each landed pixel tile in LDS by the lanes that fetched its pieces
+    // (behind their vmcnt wait, in front of the step's barrier).  Table [2][192] floats, zero past Cin (the channel tail of
+    // the last chunk stays relu(0) = 0).
+    const bool bnin = a.in_scale != nullptr;
+    float* inp = par + 3 * 96;
+    if (bnin) {
+        for (int i = tid; i < 192; i += 64 * NW) {
+            inp[i] = i < d.Cin ? a.in_scale[i] : 0.f;
+            inp[192 + i] = i < d.Cin ? a.in_shift[i] : 0.f;
+        }
+        __syncthreads();
+    }
+    int xlc[HL];                                      // 16-byte part (of the 32-channel chunk) this lane's piece i holds
+#pragma unroll
+    for (int i = 0; i < HL; ++i) xlc[i] = swz32((i * NW + wave) * 16 + (lane >> 2), lane & 3);
     const bool want_stats = a.stats != nullptr;
     float s1[NI][4], s2[NI][4];
 #pragma unroll
@@ -2387,6 +2403,21 @@ __global__ __launch_bounds__(64 * NW) void conv1x1_rs_kernel(const C3Args a, int
             } else {
                 if (patch != first) asm volatile("s_waitcnt vmcnt(%0)" : : "i"((PD - 1) * HL + L) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" : : "i"((PD - 1) * HL) : "memory");
+            }
+            if (bnin) {
+#pragma unroll
+                for (int i = 0; i < HL; ++i) {
+                    u32x4* q = (u32x4*)(sH(cb) + (i * NW + wave) * 16 * BK + lane * 8);
+                    const float* t = inp + chunk * BK + xlc[i] * 8;
+                    float f[8], sc[8], sh[8];
+                    *(f32x4*)(sc) = *(const f32x4*)(t); *(f32x4*)(sc + 4) = *(const f32x4*)(t + 4);
+                    *(f32x4*)(sh) = *(const f32x4*)(t + 192); *(f32x4*)(sh + 4) = *(const f32x4*)(t + 196);
+                    unpack8(*q, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+                    *q = pack8(f);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
 #ifdef AAU_PW_STAMP
             PW_STAMP(st_b); st_wait += st_b - st_a;
@@ -2536,9 +2567,10 @@ bool conv1x1_resw_applicable(const aau_conv_desc* d, bool want_stats) {
 
 int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
                         const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
-                        hipStream_t s) {
+                        hipStream_t s, const float* in_scale, const float* in_shift) {
     C3Args a;
     a.d = *d;
+    a.in_scale = in_scale; a.in_shift = in_shift;
     a.src = src; a.wpk = wpk; a.dst = dst; a.bias = bias; a.scale = scale; a.shift = shift; a.stats = stats;
     a.rev = next_traversal();
     a.nchunk = d->Cpad / 32;
@@ -2554,9 +2586,9 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     const size_t wbytes = ((size_t)a.nchunk * BQ * 64 + 8191) / 8192 * 8192;   // whole staging rounds of 512 threads
     // LDS: ring of pixel tiles (16 KB each) | weights | per-channel vectors
     int nbuf = 7;
-    if ((size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 > 160 * 1024) { nbuf = 2; }
+    if ((size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + 2 * 192 * 4 > 160 * 1024) { nbuf = 2; }
     if (const char* e = getenv("AAU_PW_NBUF")) { if (atoi(e) == 2) nbuf = 2; }   // A/B: round 2's one tile of look-ahead
-    const size_t lds = (size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4;
+    const size_t lds = (size_t)nbuf * 256 * 64 + wbytes + 3 * 96 * 4 + 2 * 192 * 4;      // ... | BNIN table
     int per_cu = lds <= 80 * 1024 ? 2 : 1;
     if (const char* e = getenv("AAU_PW_PERCU")) per_cu = atoi(e);   // experiment
     int gx = 256 * per_cu / ntq;
@@ -2572,6 +2604,7 @@ int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_b
     const int64_t Mo = (int64_t)d->N * d->H * d->W * (d->shuffle2x2 ? 4 : 1);
     const bool wide_ok = ((uintptr_t)dst & 15) == 0 && d->dst_pitch % 8 == 0 && (!d->shuffle2x2 || (d->Cout >> 2) % 8 == 0) && !a.nowide;
     const bool rs = nbuf == 7 && wide_ok && a.nchunk <= 6 && Mo * d->dst_pitch * 2 < 0x7fffffff && !getenv("AAU_PW_OLD");
+    if (in_scale && !rs) { set_error("aau_conv_igemm_bnin: this 1x1 problem is not served by the scalar-offset kernel (aau_conv_bnin_ok)"); return AAU_E_INVALID; }
     prof_tag(rs ? (BQ == 48 ? "conv1x1_rs<48>" : "conv1x1_rs<96>") : (BQ == 48 ? "conv1x1_resw<48>" : "conv1x1_resw<96>"));
     if (BQ == 48) {
         if (rs) { if (d->accumulate) go(conv1x1_rs_kernel<48, 8, true>); else go(conv1x1_rs_kernel<48, 8, false>); }

@@ -509,9 +509,25 @@ extern "C" int aau_conv_igemm_bnred(const aau_conv_desc* d, const aau_bf16* src,
 }
 
 
-// 1 when aau_conv_igemm_bnin serves this descriptor: a 3x3 conv that the strip kernel takes, one dense source plane
+namespace aau {
+bool conv1x1_resw_applicable(const aau_conv_desc* d, bool want_stats);
+int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
+                        const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
+                        hipStream_t s, const float* in_scale, const float* in_shift);
+}
+// the 1x1 / ConvTranspose-forward form: what conv1x1_rs_kernel takes (conv3x3.hip: 16-byte stores, at most six 32-channel chunks)
+static bool bnin_1x1_ok(const aau_conv_desc* d) {
+    return conv1x1_resw_applicable(d, false) && d->Cpad / 32 <= 6 && !d->accumulate && !d->relu && d->src_pitch % 8 == 0 &&
+           d->dst_pitch % 8 == 0 && (!d->shuffle2x2 || (d->Cout >> 2) % 8 == 0) && d->src_split_c <= 0 && d->dst_split_c <= 0 &&
+           !getenv("AAU_PW_OLD") && !getenv("AAU_PW_NBUF") && !getenv("AAU_NO_WIDE_STORE");
+}
+
+// 1 when aau_conv_igemm_bnin serves this descriptor: a 3x3 conv that the strip kernel takes, one dense source plane; or a
+// 1x1 conv / ConvTranspose2d(2,2) forward (shuffle2x2) that the scalar-offset resident-weight kernel takes
 extern "C" int aau_conv_bnin_ok(const aau_conv_desc* d) {
-    if (!d || getenv("AAU_NO_BNIN") || getenv("AAU_NO_C3S")) return 0;
+    if (!d || getenv("AAU_NO_BNIN")) return 0;
+    if (bnin_1x1_ok(d)) return 1;
+    if (getenv("AAU_NO_C3S")) return 0;
     return conv3x3_applicable(d) && (d->Cin == 48 || d->Cin == 96) && (d->Cout == 48 || d->Cout == 96) &&
            d->Cpad == (d->Cin == 48 ? 64 : 96) && !d->accumulate && !d->relu && d->src_pitch % 8 == 0 && d->dst_pitch % 8 == 0 &&
            d->src_split_c <= 0 && d->dst_split_c <= 0;
@@ -521,15 +537,24 @@ extern "C" int aau_conv_bnin_ok(const aau_conv_desc* d) {
 // bit, without the activation ever leaving the chip (pipeline:59-65: the ReLU(BatchNorm(.)) of the PRODUCING block fused
 // into the consuming convolution's operand path)
 extern "C" int aau_conv_igemm_bnin(const aau_conv_desc* d, const aau_bf16* src, const float* in_scale, const float* in_shift,
-                                   const aau_bf16* wpk, aau_bf16* dst, aau_stat* stats, int64_t stats_bytes, void* stream) {
+                                   const aau_bf16* wpk, aau_bf16* dst, const float* bias, aau_stat* stats, int64_t stats_bytes,
+                                   void* stream) {
     AAU_REQUIRE(d && src && in_scale && in_shift && wpk && dst, "aau_conv_igemm_bnin: null pointer");
     AAU_REQUIRE(aau_conv_bnin_ok(d) && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0,
                 "aau_conv_igemm_bnin: descriptor not served (aau_conv_bnin_ok) or misaligned operands");
     if (stats) AAU_CHECK_STAT("aau_conv_igemm_bnin", stats, stats_bytes, d->Cout);
     const int64_t M = (int64_t)d->N * d->H * d->W;
     const int64_t src_bytes = ((M - 1) * d->src_pitch + d->Cin) * 2;
-    AAU_REQUIRE(src_bytes < 0x7fffffff && M * d->dst_pitch * 2 < 0x7fffffff, "aau_conv_igemm_bnin: tensors must stay below 2 GiB");
+    AAU_REQUIRE(src_bytes < 0x7fffffff && M * (d->shuffle2x2 ? 4 : 1) * d->dst_pitch * 2 < 0x7fffffff,
+                "aau_conv_igemm_bnin: tensors must stay below 2 GiB");
     hipStream_t s = (hipStream_t)stream;
+    if (bnin_1x1_ok(d)) {      // 1x1 / ConvTranspose forward: the resident-weight kernel with the transform on its pixel tiles
+        ProfScope prof1(0, 2.0 * M * (double)d->Cout * d->Cin, s);
+        prof_tag(nullptr, 2.0 * ((double)M * d->Cin + (double)M * d->Cout + (double)d->Cout * d->Cin));
+        return conv1x1_resw_launch(d, src, wpk, dst, bias, nullptr, nullptr, (float*)stats, (unsigned)src_bytes,
+                                   (unsigned)((int64_t)d->Cout * d->Cpad * 2), s, in_scale, in_shift);
+    }
+    AAU_REQUIRE(bias == nullptr, "aau_conv_igemm_bnin: the 3x3 form takes no bias");
     ProfScope prof(0, 2.0 * M * (double)d->Cout * d->Cin * 9, s);
     prof_tag(nullptr, 2.0 * ((double)M * d->Cin + (double)M * d->Cout + (double)d->Cout * 9 * d->Cin));
     C3Args a;

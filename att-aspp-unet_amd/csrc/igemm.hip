@@ -106,7 +106,7 @@ int conv3x3_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* 
 bool conv1x1_resw_applicable(const aau_conv_desc* d, bool want_stats);
 int conv1x1_resw_launch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* wpk, aau_bf16* dst, const float* bias,
                         const float* scale, const float* shift, float* stats, unsigned src_bytes, unsigned wpk_bytes,
-                        hipStream_t s);
+                        hipStream_t s, const float* in_scale = nullptr, const float* in_shift = nullptr);
 
 template <int BK, int BQ, bool SMALL = false>
 static int launch(const IgemmArgs& a, hipStream_t s) {

@@ -44,6 +44,10 @@ struct WgradArgs {
     float* ws;          // split-K slabs [workgroup][9 acc tiles][256 threads][4] (null: fp32 atomics into dw)
     unsigned src_bytes, dz_bytes;   // extents for the buffer descriptors of the fast issue path
     int fast_ok;        // both tensors below 2 GiB (32-bit buffer offsets); AAU_WG_NOFAST=1 switches the path off (A/B)
+    // aau_conv_wgrad_bnin_dz: the `dz` operand is a raw conv output; relu(dz * dz_scale + dz_shift) is applied on its tile in
+    // LDS by the lanes that fetched the pieces (fast issue path only: every row of every step is a real pixel)
+    const float* dz_scale = nullptr;
+    const float* dz_shift = nullptr;
 };
 
 // byte offset of (row, channel ch [multiple of 4]) in a [rows][48*TT] bf16 tile
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     static_assert(BKP * 6 * TQ % 256 == 0 && BKP * 6 * TC % 256 == 0, "tile/threads");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (YB + XB)];
+    __shared__ __attribute__((aligned(16))) float s_dz[2 * 96];         // BNIN-dz: scale | shift of this workgroup's q tile
     auto sY = [&](int buf) -> unsigned char* { return smem + buf * (YB + XB); };
     auto sX = [&](int buf) -> unsigned char* { return smem + buf * (YB + XB) + YB; };
 
@@ -260,9 +265,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    const bool bnz = a.dz_scale != nullptr;
+    if (bnz) {
+        for (int i = tid; i < 96; i += 256) {
+            const bool in = i < 48 * TQ && q0 + i < d.Cout;
+            s_dz[i] = in ? a.dz_scale[q0 + i] : 0.f;
+            s_dz[96 + i] = in ? a.dz_shift[q0 + i] : 0.f;
+        }
+        __syncthreads();
+    }
+    // this thread's own pieces of the dz tile in buffer `buf` (they have landed: the vmcnt(0) in front of every call)
+    auto xform_y = [&](int buf) {
+        if (!bnz) return;
+#pragma unroll
+        for (int i = 0; i < NLY; ++i) {
+            u32x4* pz = (u32x4*)(sY(buf) + (256 * i + tid) * 16);
+            const float* t = s_dz + ych[i];
+            float f[8], sc[8], sh[8];
+            *(f32x4*)(sc) = *(const f32x4*)(t); *(f32x4*)(sc + 4) = *(const f32x4*)(t + 4);
+            *(f32x4*)(sh) = *(const f32x4*)(t + 96); *(f32x4*)(sh + 4) = *(const f32x4*)(t + 100);
+            unpack8(*pz, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
+            *pz = pack8(f);
+        }
+    };
     int mbase = mb;
     stage(0, mbase);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xform_y(0);
     __syncthreads();
     int buf = 0;
     while (true) {
@@ -275,6 +306,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         compute(buf);
         if (!more) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform_y(buf ^ 1);
         __syncthreads();
         buf ^= 1;
         mbase = mnext;
@@ -464,6 +496,14 @@ static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipS
     }
     a.ws = ws;
     a.rev = next_traversal();
+    if (a.dz_scale) {     // the transform needs the fast issue path in EVERY workgroup (no zero-page rows in the dz tile)
+        const bool g2 = !a.linear && d.KH == 2 && d.KW == 2 && d.stride == 2 && d.pad == 0 && d.dil == 1 && d.H == 2 * d.Ho &&
+                        d.W == 2 * d.Wo && d.Wo % BKP == 0;
+        if (!(a.fast_ok && (a.linear || g2) && a.M % BKP == 0)) {
+            set_error("aau_conv_wgrad_bnin_dz: descriptor not served (aau_conv_wgrad_bnin_dz_ok)");
+            return AAU_E_INVALID;
+        }
+    }
     {
         char tag[AAU_PROF_TAG_LEN];
         snprintf(tag, sizeof(tag), "wgrad<%d,%d>%s", TQ, TC, T > 1 ? (d.dil > 1 ? " dilated" : " taps") : "");
@@ -484,7 +524,7 @@ static int launch(WgradArgs& a, float* ws, int64_t ws_bytes, int64_t* need, hipS
 // in_scale / in_shift (aau_conv_wgrad_bnin): src is a raw conv output, the kernel applies relu(src * scale + shift) on it
 static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, float* dw, float* ws,
                           int64_t ws_bytes, int64_t* need, void* stream, const float* in_scale = nullptr,
-                          const float* in_shift = nullptr) {
+                          const float* in_shift = nullptr, const float* dz_scale = nullptr, const float* dz_shift = nullptr) {
     using namespace aau;
     AAU_REQUIRE(d, "aau_conv_wgrad: null descriptor");
     AAU_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0 && d->Cout > 0 && d->Cout % 8 == 0,
@@ -501,6 +541,8 @@ static int wgrad_dispatch(const aau_conv_desc* d, const aau_bf16* src, const aau
     WgradArgs a;
     a.d = *d;
     a.src = src; a.dz = dz; a.dw = dw; a.ws = nullptr;
+    a.dz_scale = dz_scale; a.dz_shift = dz_shift;
+    if (dz_scale) AAU_REQUIRE(aau_conv_wgrad_bnin_dz_ok(d), "aau_conv_wgrad_bnin_dz: descriptor not served (aau_conv_wgrad_bnin_dz_ok)");
     a.M = d->N * d->Ho * d->Wo;
     a.linear = (d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo);
     {
@@ -556,6 +598,25 @@ extern "C" int aau_conv_wgrad(const aau_conv_desc* d, const aau_bf16* src, const
 extern "C" int aau_conv_wgrad_ws_bytes(const aau_conv_desc* d, int64_t* bytes) {
     AAU_REQUIRE(bytes, "aau_conv_wgrad_ws_bytes: null pointer");
     return wgrad_dispatch(d, nullptr, nullptr, nullptr, nullptr, 0, bytes, nullptr);
+}
+
+// 1 when aau_conv_wgrad_bnin_dz serves this descriptor: the generic kernel's fast issue path in every workgroup
+extern "C" int aau_conv_wgrad_bnin_dz_ok(const aau_conv_desc* d) {
+    using namespace aau;
+    if (!d || getenv("AAU_NO_BNIN") || getenv("AAU_WG_NOFAST") || wgrad3x3_applicable(d)) return 0;
+    const bool lin = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->H == d->Ho && d->W == d->Wo;
+    const bool g2 = d->KH == 2 && d->KW == 2 && d->stride == 2 && d->pad == 0 && d->dil == 1 && d->H == 2 * d->Ho && d->W == 2 * d->Wo &&
+                    d->Wo % 128 == 0;
+    const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+    const int64_t sbytes = (((int64_t)d->N * d->H * d->W - 1) * d->src_pitch + d->Cin) * 2, zbytes = ((M - 1) * d->dst_pitch + d->Cout) * 2;
+    return (lin || g2) && M % 128 == 0 && sbytes < 0x7fffffff && zbytes < 0x7fffffff && d->src_split_c <= 0 && d->dst_split_c <= 0 &&
+           d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->src_pitch % 8 == 0 && d->dst_pitch % 8 == 0;
+}
+
+extern "C" int aau_conv_wgrad_bnin_dz(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, const float* dz_scale,
+                                      const float* dz_shift, float* dw, float* ws, int64_t ws_bytes, void* stream) {
+    AAU_REQUIRE(dz_scale && dz_shift, "aau_conv_wgrad_bnin_dz: null pointer");
+    return wgrad_dispatch(d, src, dz, dw, ws, ws_bytes, nullptr, stream, nullptr, nullptr, dz_scale, dz_shift);
 }
 
 // 1 when aau_conv_wgrad_bnin serves this descriptor (the all-taps 3x3 kernel, one source plane)

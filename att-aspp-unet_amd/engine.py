@@ -85,11 +85,14 @@ class _Rec:
         self.ops.append((f, tuple(conv), name, 1 if side else 0, self.label))
         self.uses_side |= side
 
-    def add_wgrad(self, desc, src, dz, dw, side=False, src_bn=None):
+    def add_wgrad(self, desc, src, dz, dw, side=False, src_bn=None, dz_bn=None):
         """aau_conv_wgrad with the shared split-K workspace, which is sized and patched in by ``bind_wgrad_ws``.
         ``src_bn`` = (scale, shift): ``src`` is the raw conv output of the producing layer and its BatchNorm + ReLU is applied
-        on the operand inside the kernel (aau_conv_wgrad_bnin)."""
-        if src_bn is None:
+        on the operand inside the kernel (aau_conv_wgrad_bnin); ``dz_bn``: the same for the ``dz`` operand (the coarse input
+        activation of a ConvTranspose2d, aau_conv_wgrad_bnin_dz)."""
+        if dz_bn is not None:
+            self.add("aau_conv_wgrad_bnin_dz", desc, src, dz, dz_bn[0], dz_bn[1], dw, None, 0, side=side)
+        elif src_bn is None:
             self.add("aau_conv_wgrad", desc, src, dz, dw, None, 0, side=side)
         else:
             self.add("aau_conv_wgrad_bnin", desc, src, src_bn[0], src_bn[1], dz, dw, None, 0, side=side)
@@ -469,7 +472,7 @@ class Plan:
                 rec["z"] = z
                 return rec
             if src_bn is not None:
-                self.fwd.add("aau_conv_igemm_bnin", d, src, src_bn[0], src_bn[1], cv.pk_f, z, w["stats"])
+                self.fwd.add("aau_conv_igemm_bnin", d, src, src_bn[0], src_bn[1], cv.pk_f, z, None, w["stats"])
             else:
                 self.fwd.add("aau_conv_igemm", d, src, cv.pk_f, z, None, None, None, w["stats"])
             self._bn_finalize(bn, w, M)
@@ -739,6 +742,7 @@ class Plan:
         # ---------------- decoder ----------------
         dec = []
         g_in, g_c = bout, Cb
+        g_bn = None      # (scale, shift) when g_in is the RAW output of the previous level's last ConvBNReLU (activation not stored)
         for lv in (3, 2, 1, 0):
             name = f"u{lv + 1}"
             Co = Cs[lv]
@@ -749,7 +753,10 @@ class Plan:
             kind = gate_kinds[lv]
             dup = ops.conv_desc(B, hi, wi, g_c, g_c, hi, wi, 4 * Co, cat_p[lv], Cpad=up.cpad_f, shuffle2x2=1)
             f.label = f"{name}.up"
-            f.add("aau_conv_igemm", dup, g_in, up.pk_f, hi_(cat, lv), up.bias, None, None, None)
+            if g_bn is not None:     # the previous level's BatchNorm + ReLU on the transposed conv's operand
+                f.add("aau_conv_igemm_bnin", dup, g_in, g_bn[0], g_bn[1], up.pk_f, hi_(cat, lv), up.bias, None)
+            else:
+                f.add("aau_conv_igemm", dup, g_in, up.pk_f, hi_(cat, lv), up.bias, None, None, None)
             gate = None
             if kind == "res":
                 wg, wx, psi = st.convs[f"{name}.att.Wg"], st.convs[f"{name}.att.Wx"], st.convs[f"{name}.att.psi.1"]
@@ -814,13 +821,22 @@ class Plan:
             ra = self.cbr_fwd(f"{name}.conv.0.block.0", f"{name}.conv.0.block.1", cat, cat_p[lv], B, ho, wo, ya, Co,
                               src_split=cat_split[lv], skip_act=bnin)
             fuse_head = tr and lv == 0 and not eng.no_fuse_head
-            yb = None if fuse_head else self.new(Mo, Co)
+            # the activation of this level's last ConvBNReLU feeds the next level's transposed conv alone: where that conv's
+            # forward and weight-gradient kernels apply BatchNorm + ReLU on their operand, it is not stored either
+            up_bnin = False
+            if tr and lv > 0 and not eng.no_bnin and not eng.no_bnin_up:
+                Cn, upn = Cs[lv - 1], st.convs[f"u{lv}.up"]
+                dn = ops.conv_desc(B, ho, wo, Co, Co, ho, wo, 4 * Cn, cat_p[lv - 1], Cpad=upn.cpad_f, shuffle2x2=1)
+                un = ops.conv_desc(B, Hs[lv - 1], Ws[lv - 1], Cn, cat_p[lv - 1], ho, wo, Co, Co, 2, 2, 2, 0, 1)
+                up_bnin = ops.conv_bnin_ok(dn) and ops.conv_wgrad_bnin_dz_ok(un)
+            yb = None if (fuse_head or up_bnin) else self.new(Mo, Co)
             rb = self.cbr_fwd(f"{name}.conv.1.block.0", f"{name}.conv.1.block.1", ra["z"] if bnin else ya, Co, B, ho, wo,
                               yb, Co, head=st.convs["out_conv"] if fuse_head else None,
-                              src_bn=(ra["w"]["scale"], ra["w"]["shift"]) if bnin else None)
-            dec.append(dict(lv=lv, name=name, up=up, cat=cat, gate=gate, ra=ra, rb=rb, g_in=g_in, g_c=g_c, Co=Co,
+                              src_bn=(ra["w"]["scale"], ra["w"]["shift"]) if bnin else None, skip_act=up_bnin)
+            dec.append(dict(lv=lv, name=name, up=up, cat=cat, gate=gate, ra=ra, rb=rb, g_in=g_in, g_c=g_c, g_bn=g_bn, Co=Co,
                             hi=hi, wi=wi, ho=ho, wo=wo, Mo=Mo, out=yb))
-            g_in, g_c = yb, Co
+            g_in, g_c = (rb["z"] if up_bnin else yb), Co
+            g_bn = (rb["w"]["scale"], rb["w"]["shift"]) if up_bnin else None
         oc = st.convs["out_conv"]
         fused_head = g_in is None
         f.label = "out_conv"
@@ -916,7 +932,7 @@ class Plan:
                 # rides along in the bridge's grouped launch below instead of half-filling the chip on its own
                 pre_wg.append((upd, dcat_hi, gsrc, up.dw, b.label))
             else:
-                b.add_wgrad(upd, dcat_hi, gsrc, up.dw, side=ov)
+                b.add_wgrad(upd, dcat_hi, gsrc, up.dw, side=ov, dz_bn=blk["g_bn"])
             dg_in = self.new(B * hi * wi, gc)
             b.add("aau_conv_igemm", ops.conv_desc(B, ho, wo, Co, cat_p[lv], hi, wi, gc, gc, 2, 2, 2, 0, 1, up.cpad_d),
                   dcat_hi, up.pk_d, dg_in, None, None, None, None)
@@ -1088,6 +1104,7 @@ class Engine:
         self.no_fuse_bnred = os.environ.get("AAU_NO_BNRED", "0") == "1"
         self.no_bnin = os.environ.get("AAU_NO_BNIN", "0") == "1"     # A/B: ConvBNReLU pairs with the activation in memory
         self.no_bn_multi = os.environ.get("AAU_NO_BN_MULTI", "0") == "1"   # A/B: one BatchNorm launch per ASPP branch
+        self.no_bnin_up = os.environ.get("AAU_NO_BNIN_UP", "0") == "1"    # A/B: the activation in front of a transposed conv stays in memory
         self.bnin_max_c = int(os.environ.get("AAU_BNIN_MAX_C", "96"))     # A/B: widest producing layer whose BN + ReLU moves onto the operand
         # opt-in (measured +0.04 ms on the step): the pooled layers' apply pass redoes the max-pool routing instead of
         # reading the routed gradient the reduce pass stored

@@ -231,12 +231,12 @@ def conv_bnin_ok(desc: ConvDesc) -> bool:
     return bool(fn("aau_conv_bnin_ok")(C.byref(desc)))
 
 
-def conv_igemm_bnin(desc: ConvDesc, src, in_scale, in_shift, wpk, dst, stats=None):
+def conv_igemm_bnin(desc: ConvDesc, src, in_scale, in_shift, wpk, dst, stats=None, bias=None):
     """dst = conv(relu(src * in_scale + in_shift)): the producing layer's BatchNorm + ReLU applied on the operand in LDS
     (include/aau.h: bit for bit aau_bn_act followed by aau_conv_igemm)."""
     if stats is not None:
         _check_stats(stats, desc.Cout, "conv_igemm_bnin")
-    check(fn("aau_conv_igemm_bnin")(C.byref(desc), _p(src), _p(in_scale), _p(in_shift), _p(wpk), _p(dst), _p(stats),
+    check(fn("aau_conv_igemm_bnin")(C.byref(desc), _p(src), _p(in_scale), _p(in_shift), _p(wpk), _p(dst), _p(bias), _p(stats),
                                     _nb(stats) if stats is not None else 0, _stream()), "aau_conv_igemm_bnin")
 
 
@@ -249,6 +249,17 @@ def conv_wgrad_bnin(desc: ConvDesc, src, in_scale, in_shift, dz, dw, ws=None):
     nb = 0 if ws is None else ws.numel() * ws.element_size()
     check(fn("aau_conv_wgrad_bnin")(C.byref(desc), _p(src), _p(in_scale), _p(in_shift), _p(dz), _p(dw), _p(ws), nb, _stream()),
           "aau_conv_wgrad_bnin")
+
+
+def conv_wgrad_bnin_dz_ok(desc: ConvDesc) -> bool:
+    return bool(fn("aau_conv_wgrad_bnin_dz_ok")(C.byref(desc)))
+
+
+def conv_wgrad_bnin_dz(desc: ConvDesc, src, dz, dz_scale, dz_shift, dw, ws=None):
+    """dw += weight gradient with relu(dz * dz_scale + dz_shift) as the `dz` operand (include/aau.h: ConvTranspose2d)."""
+    nb = 0 if ws is None else ws.numel() * ws.element_size()
+    check(fn("aau_conv_wgrad_bnin_dz")(C.byref(desc), _p(src), _p(dz), _p(dz_scale), _p(dz_shift), _p(dw), _p(ws), nb, _stream()),
+          "aau_conv_wgrad_bnin_dz")
 
 
 def stats_to_red(stats, Cc, red):

@@ -131,16 +131,28 @@ int aau_stats_to_red(const aau_stat* stats, int64_t stats_bytes, int C, float* r
 /* ConvBNReLU), pipeline:113): src is the RAW conv output z of the producing layer and in_scale / in_shift its folded   */
 /* BatchNorm affine (aau_bn_finalize); the kernel applies y = relu(z * in_scale + in_shift) in LDS behind the landing     */
 /* fill, so dst (+ stats) equals aau_bn_act followed by aau_conv_igemm BIT FOR BIT while y is never written or read.      */
-/* Served for the descriptors aau_conv_bnin_ok() accepts (3x3, 48 / 96 channels in and out: the strip kernel).            */
+/* Served for the descriptors aau_conv_bnin_ok() accepts: 3x3 with 48 / 96 channels in and out (the strip kernel), and      */
+/* the 1x1 / ConvTranspose2d(2,2)-forward (shuffle2x2, pipeline:101 behind a ConvBNReLU pair, :116-120) problems of the      */
+/* resident-weight kernel (H, W multiples of 16, at most 192 input channels); `bias` (1x1 form only, else NULL) as in        */
+/* aau_conv_igemm.                                                                                                           */
 int aau_conv_bnin_ok(const aau_conv_desc* d);
 int aau_conv_igemm_bnin(const aau_conv_desc* d, const aau_bf16* src, const float* in_scale, const float* in_shift,
-                        const aau_bf16* wpk, aau_bf16* dst, aau_stat* stats, int64_t stats_bytes, void* stream);
+                        const aau_bf16* wpk, aau_bf16* dst, const float* bias, aau_stat* stats, int64_t stats_bytes,
+                        void* stream);
 /* ... and the same for the weight gradient of that convolution: x = relu(src * in_scale + in_shift) applied in LDS, */
 /* dw += as aau_conv_wgrad (workspace: aau_conv_wgrad_ws_bytes of the same descriptor).  aau_conv_wgrad_bnin_ok():       */
 /* descriptors that take the all-taps 3x3 kernel.                                                                       */
 int aau_conv_wgrad_bnin_ok(const aau_conv_desc* d);
 int aau_conv_wgrad_bnin(const aau_conv_desc* d, const aau_bf16* src, const float* in_scale, const float* in_shift,
                         const aau_bf16* dz, float* dw, float* ws, int64_t ws_bytes, void* stream);
+/* The weight gradient of a ConvTranspose2d(2,2) (pipeline:101) is stated as aau_conv_wgrad of the 2x2 / stride-2 problem    */
+/* with the FINE gradient as `src` and the coarse input activation as `dz`; when that activation was never stored, `dz` is   */
+/* the producing layer's raw conv output and dz' = relu(dz * dz_scale + dz_shift) is applied on the operand in LDS.  Served   */
+/* for the descriptors aau_conv_wgrad_bnin_dz_ok() accepts (1x1, or 2x2 / stride 2 with Wo a multiple of 128; M a multiple   */
+/* of 128).                                                                                                                  */
+int aau_conv_wgrad_bnin_dz_ok(const aau_conv_desc* d);
+int aau_conv_wgrad_bnin_dz(const aau_conv_desc* d, const aau_bf16* src, const aau_bf16* dz, const float* dz_scale,
+                           const float* dz_shift, float* dw, float* ws, int64_t ws_bytes, void* stream);
 
 /* 1 when the launch this descriptor selects supports its two-plane operands (src_split_c /  */
 /* dst_split_c): mode 0 = aau_conv_igemm (the resident-weight 3x3 kernels), 1 = aau_conv_wgrad */

@@ -983,3 +983,75 @@ def test_round4_1x1_kernel_equals_the_ring_kernel_it_replaces(ops, case, monkeyp
     if st_new is not None:      # (the per-workgroup fp32 partial sums contract differently in the two instantiations: last bits)
         a, b = ops.stats_totals(st_new, Cout), ops.stats_totals(st_old, Cout)
         assert float(((a - b).abs() / (b.abs() + 1.0)).max()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(4, 256, 256, 96, 48, 0), (4, 256, 256, 40, 104, 0), (4, 256, 256, 96, 192, 1),
+                                  (8, 128, 128, 192, 384, 1), (2, 256, 256, 64, 192, 2)])
+def test_1x1_and_convT_forward_with_batchnorm_relu_applied_on_the_input(ops, case):
+    """aau_conv_igemm_bnin on the resident-weight 1x1 kernel (conv1x1_rs): the same bits as aau_bn_act into a buffer followed
+    by aau_conv_igemm -- plain 1x1 with statistics, ConvTranspose forward (pixel shuffle + bias) into a dense plane (mode 1)
+    and into the upper half of an interleaved concat buffer (mode 2), a channel tail in the last 32-channel chunk."""
+    N, H, W, Cin, Cout, mode = case
+    g = torch.Generator().manual_seed(7000 + sum(case))
+    z = (torch.randn(N * H * W, Cin, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    scale, shift = torch.randn(Cin, generator=g).cuda(), (torch.randn(Cin, generator=g) * 0.5 + 0.3).cuda()
+    cp = ops.cpad_of(Cin)
+    w = torch.zeros(Cout, 1, cp)
+    w[:, 0, :Cin] = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
+    w = w.to(torch.bfloat16).cuda()
+    if mode == 0:
+        d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, Cout, Cpad=cp)
+        shape, view, bias = (N * H * W, Cout), (lambda t: t), None
+    else:
+        Co = Cout // 4
+        pitch = Co if mode == 1 else 2 * Co
+        d = ops.conv_desc(N, H, W, Cin, Cin, H, W, Cout, pitch, Cpad=cp, shuffle2x2=1)
+        shape, view = (N * 4 * H * W, pitch), (lambda t: t if mode == 1 else t[:, Co:])
+        bias = torch.randn(Co, generator=g).cuda()
+    assert ops.conv_bnin_ok(d)
+    y = torch.empty_like(z)
+    ops.bn_act(z, Cin, y, Cin, scale, shift, N * H * W, Cin)
+    ref = torch.full(shape, 2.0, dtype=torch.bfloat16, device="cuda")
+    st_ref = ops.stats_buffer(Cout) if mode == 0 else None
+    ops.conv_igemm(d, y, w, view(ref), bias=bias, stats=st_ref)
+    got = torch.full(shape, 2.0, dtype=torch.bfloat16, device="cuda")
+    st = ops.stats_buffer(Cout) if mode == 0 else None
+    with launch_tags() as lt:
+        ops.conv_igemm_bnin(d, z, scale, shift, w, view(got), stats=st, bias=bias)
+    torch.cuda.synchronize()
+    assert lt[0].startswith("conv1x1_rs<"), lt
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    if st is not None:
+        a, b = ops.stats_totals(st, Cout), ops.stats_totals(st_ref, Cout)
+        assert float(((a - b).abs() / (b.abs() + 1.0)).max()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [("taps", 1, 128, 128, 48, 96), ("taps", 2, 64, 128, 96, 192), ("lin", 2, 64, 64, 96, 48),
+                                  ("lin", 1, 128, 128, 192, 96)])
+def test_weight_gradient_with_batchnorm_relu_applied_on_the_dz_operand(ops, case):
+    """aau_conv_wgrad_bnin_dz (the ConvTranspose2d weight gradient, whose `dz` operand is the coarse input activation): the
+    same bits as aau_bn_act on that operand followed by aau_conv_wgrad, through the deterministic split-K workspace."""
+    kind, N, Ho, Wo, Cs, Cq = case            # Cs: channels of `src`, Cq: channels of the `dz` operand
+    g = torch.Generator().manual_seed(8000 + N + Ho + Cs + Cq)
+    k = 2 if kind == "taps" else 1
+    H, W = Ho * k, Wo * k
+    src = torch.randn(N * H * W, Cs, generator=g).to(torch.bfloat16).cuda()
+    zq = (torch.randn(N * Ho * Wo, Cq, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    scale, shift = torch.randn(Cq, generator=g).cuda(), (torch.randn(Cq, generator=g) * 0.5 + 0.3).cuda()
+    if kind == "taps":
+        d = ops.conv_desc(N, H, W, Cs, Cs, Ho, Wo, Cq, Cq, 2, 2, 2, 0, 1)
+    else:
+        d = ops.conv_desc(N, H, W, Cs, Cs, Ho, Wo, Cq, Cq, 1, 1, 1, 0, 1)
+    assert ops.conv_wgrad_bnin_dz_ok(d)
+    ws = torch.full((ops.conv_wgrad_ws_bytes(d) // 4,), float("nan"), device="cuda")
+    act = torch.empty_like(zq)
+    ops.bn_act(zq, Cq, act, Cq, scale, shift, N * Ho * Wo, Cq)
+    ref = torch.zeros(Cq, k * k, Cs, device="cuda")
+    ops.conv_wgrad(d, src, act, ref, ws)
+    got = torch.zeros(Cq, k * k, Cs, device="cuda")
+    ops.conv_wgrad_bnin_dz(d, src, zq, scale, shift, got, ws)
+    torch.cuda.synchronize()
+    assert float(ref.abs().max()) > 0 and torch.equal(got, ref)
+    with pytest.raises(Exception, match="not served"):        # the all-taps 3x3 kernel has its own form (aau_conv_wgrad_bnin)
+        d3 = ops.conv_desc(N, Ho, Wo, Cs, Cs, Ho, Wo, Cq, Cq, 3, 3, 1, 1, 1)
+        ops.conv_wgrad_bnin_dz(d3, src[: N * Ho * Wo], zq, scale, shift, torch.zeros(Cq, 9, Cs, device="cuda"), ws)

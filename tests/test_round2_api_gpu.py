@@ -295,7 +295,7 @@ def test_experiment_switches_do_not_change_the_result(A, switch, monkeypatch):
 
 
 @pytest.mark.parametrize("switch", ["AAU_NO_BNRED", "AAU_NO_IGEMM_MULTI", "AAU_NO_POOLBRANCH", "AAU_BRIDGE_WG_SIDE", "AAU_NO_BNIN",
-                                    "AAU_NO_BN_MULTI"])
+                                    "AAU_NO_BN_MULTI", "AAU_NO_BNIN_UP"])
 def test_default_on_fused_paths_against_their_off_switches_at_the_metric_shape(A, switch, monkeypatch):
     """Whole-step A/B of the fused paths that are ON by default, at the shape where they engage (base_c 48, 8 x 512 x 512:
     48-channel strip levels -> aau_conv_igemm_bnred; bridge 384 -> 768 on 8192 pixels = 256 wide tiles per branch ->
@@ -322,12 +322,14 @@ def test_default_on_fused_paths_against_their_off_switches_at_the_metric_shape(A
 
     la, ga, na = run()
     assert "aau_conv_igemm_bnred" in na and "aau_conv_igemm_multi" in na and "aau_poolbranch_fwd" in na
-    assert na.count("aau_conv_igemm_bnin") == 4 and na.count("aau_conv_wgrad_bnin") == 4      # d1.1, d2.1, u2.conv.1, u1.conv.1
+    # d1.1, d2.1, u2.conv.1, u1.conv.1; u2.up and u1.up (the activation in front of a transposed conv)
+    assert na.count("aau_conv_igemm_bnin") == 6 and na.count("aau_conv_wgrad_bnin") == 4 and na.count("aau_conv_wgrad_bnin_dz") == 2
     monkeypatch.setenv(switch, "1")
     lb, gb, nb = run()
     assert "aau_bn_finalize_multi" in na and "aau_bn_bwd_apply_multi" in na
     off = {"AAU_NO_BNRED": "aau_conv_igemm_bnred", "AAU_NO_POOLBRANCH": "aau_poolbranch_fwd",
-           "AAU_NO_BNIN": "aau_conv_igemm_bnin", "AAU_NO_BN_MULTI": "aau_bn_finalize_multi"}.get(switch)
+           "AAU_NO_BNIN": "aau_conv_igemm_bnin", "AAU_NO_BN_MULTI": "aau_bn_finalize_multi",
+           "AAU_NO_BNIN_UP": "aau_conv_wgrad_bnin_dz"}.get(switch)
     if off:
         assert off not in nb
     if switch == "AAU_NO_IGEMM_MULTI":
