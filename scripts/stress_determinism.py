@@ -281,4 +281,38 @@ def run_poolbranch(name, reps=20):
 
 
 tot += run_poolbranch("poolbranch fwd / bwd / dx")
+
+
+def run_bnin_up(name, N, H, Ci, Co, reps=12):
+    """ConvTranspose2d(2,2) with BatchNorm + ReLU applied on its operand: forward (conv1x1_rs, own-piece rewrite of the pixel
+    tiles) and weight gradient (wgrad_kernel, the dz operand)"""
+    z = (torch.randn(N * H * H, Ci, device="cuda") * 1.5).to(torch.bfloat16)
+    dfine = torch.randn(N * 4 * H * H, Co, device="cuda").to(torch.bfloat16)
+    cp = ops.cpad_of(Ci)
+    w = (torch.randn(4 * Co, 1, cp, device="cuda") / Ci ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(Co, device="cuda")
+    sc, sh = torch.randn(Ci, device="cuda"), torch.randn(Ci, device="cuda") * 0.5 + 0.3
+    df = ops.conv_desc(N, H, H, Ci, Ci, H, H, 4 * Co, Co, Cpad=cp, shuffle2x2=1)
+    dw_ = ops.conv_desc(N, 2 * H, 2 * H, Co, Co, H, H, Ci, Ci, 2, 2, 2, 0, 1)
+    assert ops.conv_bnin_ok(df) and ops.conv_wgrad_bnin_dz_ok(dw_)
+    ws = torch.full((ops.conv_wgrad_ws_bytes(dw_) // 4,), float("nan"), device="cuda")
+    other = torch.randn(64 << 20, device="cuda")
+    outs, dws = [], []
+    for r in range(reps):
+        out = torch.full((N * 4 * H * H, Co), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dw = torch.zeros(Ci, 4, Co, device="cuda")
+        if r % 3 == 1: other.mul_(1.0001)
+        ops.conv_igemm_bnin(df, z, sc, sh, w, out, bias=bias)
+        ops.conv_wgrad_bnin_dz(dw_, dfine, z, sc, sh, dw, ws)
+        if r % 3 == 2: other.add_(1e-3)
+        outs.append(out); dws.append(dw)
+    torch.cuda.synchronize()
+    bad = sum(0 if (torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) and torch.equal(g, dws[0])) else 1
+              for o, g in zip(outs[1:], dws[1:]))
+    print(f"{name:28s} mismatching repeats {bad}/{reps-1}  nan {int(torch.isnan(outs[0].float()).sum()) + int(torch.isnan(dws[0]).sum())}", flush=True)
+    return bad
+
+
+tot += run_bnin_up("bnin ConvT fwd + wgrad 256 96->48", 8, 256, 96, 48)
+tot += run_bnin_up("bnin ConvT fwd + wgrad 128 192->96", 8, 128, 192, 96)
 print("TOTAL mismatches", tot)
